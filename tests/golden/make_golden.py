@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (read-only, in this container only).
+
+Run:  python tests/golden/make_golden.py [--only NAME ...]
+
+The reference lives at /root/reference and never travels to the GPU box, so what is
+committed here is DATA only: inputs (FASTA, gz) and the reference's outputs for them
+(.npz).  Nothing below copies reference source; the reference functions are called in
+place (functions.get_orfs / functions.get_graph) and their local
+variables are observed with sys.setprofile.
+
+The shortest path is NOT computed by the reference's solver (fastpathz is an external
+package absent from this container and from /root/reference — SURVEY.md §2 row 8), so the
+path part of every fixture is produced by the exact-integer Bellman-Ford below, which
+restates what phanotate.py:56-67 feeds to / reads from fastpathz: edges in
+Graph.iteredges order, weight = trunc(Decimal_weight*1000) as an arbitrary-precision
+int, in-place relaxation with strict '<', V-1 rounds with early exit.  It is cross-checked
+against the only pinned results the reference repo holds (README.md:45-54, phiX174).
+"""
+import argparse
+import ctypes
+import gzip
+import io
+import os
+import sys
+import time
+from decimal import Decimal
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+from phanotate_modules import functions  # noqa: E402  (the reference, imported in place)
+from phanotate_modules.edges import Edge  # noqa: E402
+
+D = Decimal
+
+
+class StubLocus:
+    """What functions.get_orfs needs from a genbank Locus (phanotate.py:42-44, orfs.py:8-15)."""
+
+    def __init__(self, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05", stop_codons="tag,tga,taa", minlen=90):
+        self._seq = seq
+        sc = dict()
+        for codon, weight in map(lambda x: tuple(x.split(":")), start_codons.split(",")):
+            sc[codon.lower()] = D(weight)
+        m = max(sc.values())
+        self.start_codons = {k: v / m for k, v in sc.items()}  # file_handling.py:58-62
+        self.stop_codons = [c.lower() for c in stop_codons.split(",")]
+        self.min_orf_len = minlen
+
+    def seq(self):
+        return self._seq
+
+
+def read_fasta(path):
+    op = gzip.open if path.endswith(".gz") else open
+    name, seq = None, []
+    with op(path, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    break
+                name = line[1:].split()[0]
+            else:
+                seq.append(line.strip())
+    return name, "".join(seq)
+
+
+def run_reference(locus):
+    """get_orfs + get_graph, capturing get_orfs' locals on return."""
+    captured = {}
+
+    def prof(frame, event, arg):
+        if event == "return" and frame.f_code.co_name == "get_orfs":
+            loc = frame.f_locals
+            for k in ("background_rbs", "training_rbs", "pos_max", "pos_min", "gc_pos_freq"):
+                captured[k] = loc[k]
+
+    t0 = time.time()
+    sys.setprofile(prof)
+    try:
+        orfs = functions.get_orfs(locus)
+    finally:
+        sys.setprofile(None)
+    t1 = time.time()
+    graph = functions.get_graph(orfs)
+    t2 = time.time()
+    return orfs, graph, captured, (t1 - t0, t2 - t1)
+
+
+def trunc_int(dec):
+    """Decimal -> int, truncation toward zero (fastpathz drops the fractional digits)."""
+    return int(dec)
+
+
+def bellman_ford(nodes, edges, src, dst):
+    """Exact-integer in-place Bellman-Ford over the edge list in the given order."""
+    idx = {n: i for i, n in enumerate(nodes)}
+    E = [(idx[e.source], idx[e.target], trunc_int(e.weight * 1000)) for e in edges]
+    V = len(nodes)
+    INF = None
+    dist = [INF] * V
+    par = [-1] * V
+    dist[idx[src]] = 0
+    rounds = 0
+    for _ in range(V - 1):
+        changed = False
+        rounds += 1
+        for (u, v, w) in E:
+            du = dist[u]
+            if du is None:
+                continue
+            nd = du + w
+            if dist[v] is None or nd < dist[v]:
+                dist[v] = nd
+                par[v] = u
+                changed = True
+        if not changed:
+            break
+    t = idx[dst]
+    if dist[t] is None:
+        return [], None, rounds, E
+    path = [t]
+    while path[-1] != idx[src]:
+        path.append(par[path[-1]])
+    path.reverse()
+    return path, dist[t], rounds, E
+
+
+TYPE_CODE = {"start": 0, "stop": 1, "source": 2, "target": 3}
+
+
+def make_case(case, name, seq, outdir, **params):
+    locus = StubLocus(seq, **params)
+    out = {"name": name, "L": len(seq)}
+    out["params_start"] = ",".join("%s:%s" % (k, v) for k, v in locus.start_codons.items())
+    out["params_stop"] = ",".join(locus.stop_codons)
+    out["params_minlen"] = locus.min_orf_len
+    try:
+        orfs, graph, cap, times = run_reference(locus)
+    except Exception as e:  # reference aborts the run: record which way
+        out["error"] = type(e).__name__
+        np.savez_compressed(os.path.join(outdir, case + ".npz"), **{k: np.array(v) for k, v in out.items()})
+        print("%-22s L=%-7d reference raised %s" % (case, len(seq), out["error"]))
+        return
+    out["error"] = ""
+    out["ref_seconds"] = np.array(times)
+    out["pstop"] = float(orfs.pstop)
+    out["pstop_str"] = str(orfs.pstop)
+    out["background_rbs"] = np.array(cap["background_rbs"], dtype=np.float64)
+    out["training_rbs"] = np.array(cap["training_rbs"], dtype=np.float64)
+    out["pos_max"] = np.array([float(x) for x in cap["pos_max"]])
+    out["pos_min"] = np.array([float(x) for x in cap["pos_min"]])
+    out["gc_pos_freq"] = np.array(cap["gc_pos_freq"], dtype=np.int16)  # [L-1][3], row 0 is a dummy
+
+    ol = list(orfs.iter_orfs())
+    out["orf_start"] = np.array([o.start for o in ol], dtype=np.int32)
+    out["orf_stop"] = np.array([o.stop for o in ol], dtype=np.int32)
+    out["orf_frame"] = np.array([o.frame for o in ol], dtype=np.int32)
+    out["orf_length"] = np.array([o.length for o in ol], dtype=np.int32)
+    out["orf_rbs"] = np.array([o.rbs_score for o in ol], dtype=np.int32)
+    out["orf_pstop"] = np.array([float(o.pstop) for o in ol])
+    out["orf_weight_rbs"] = np.array([float(o.weight_rbs) for o in ol])
+    out["orf_log10_hold"] = np.array([float(D(o.hold).log10()) if o.hold != 0 else -np.inf for o in ol])
+    out["orf_weight"] = np.array([float(o.weight) for o in ol])
+    out["orf_weight_str"] = np.array([str(o.weight) for o in ol])
+    ks = sorted(k for k in orfs.other_end if isinstance(k, int))
+    out["other_end_key"] = np.array(ks, dtype=np.int32)
+    out["other_end_val"] = np.array([orfs.other_end[k] for k in ks], dtype=np.int32)
+
+    nodes = list(graph.iternodes())
+    nidx = {n: i for i, n in enumerate(nodes)}
+    out["node_type"] = np.array([TYPE_CODE[n.type] for n in nodes], dtype=np.int8)
+    out["node_frame"] = np.array([n.frame for n in nodes], dtype=np.int8)
+    out["node_pos"] = np.array([n.position for n in nodes], dtype=np.int32)
+    edges = list(graph.iteredges())
+    out["edge_src"] = np.array([nidx[e.source] for e in edges], dtype=np.int32)
+    out["edge_dst"] = np.array([nidx[e.target] for e in edges], dtype=np.int32)
+    out["edge_weight"] = np.array([float(e.weight) for e in edges])
+    import hashlib
+
+    h = hashlib.md5()
+    for e in edges:
+        h.update((str(e) + "\n").encode())  # == the reference's --dump text (phanotate.py:58)
+    out["dump_md5"] = h.hexdigest()
+
+    src = nodes[-2] if len(nodes) >= 2 else None
+    dst = nodes[-1] if len(nodes) >= 2 else None
+    genes = []
+    tab = io.StringIO()
+    tab.write("#id:\t" + name + "\n")
+    tab.write("#START\tSTOP\tFRAME\tCONTIG\tSCORE\n")
+    if len(graph) > 2:  # phanotate.py:63
+        path, dist, rounds, E = bellman_ford(nodes, edges, src, dst)
+        out["edge_wint"] = np.array([str(w) for (_, _, w) in E])
+        out["path"] = np.array(path, dtype=np.int32)
+        out["path_dist"] = str(dist)
+        out["bf_rounds"] = rounds
+        sp = path[1:]  # phanotate.py:65
+        it = iter(sp)
+        for a, b in zip(it, it):  # file_handling.pairwise (phanotate.py:71)
+            left, right = nodes[a], nodes[b]
+            w = graph.weight(Edge(left, right, 0))
+            strand = -1 if left.frame < 0 else 1
+            l, r = left.position, right.position + 2  # locus.py:30
+            genes.append((l, r, strand, float(w)))
+            a_, b_ = (l, r) if strand > 0 else (r, l)  # locus.py:44-46
+            tab.write("%d\t%d\t%s\t%s\t%s\n" % (a_, b_, chr(44 - strand), name, "%E" % w))
+    else:
+        out["edge_wint"] = np.array([], dtype="U1")
+        out["path"] = np.array([], dtype=np.int32)
+        out["path_dist"] = ""
+        out["bf_rounds"] = 0
+    out["gene_left"] = np.array([g[0] for g in genes], dtype=np.int32)
+    out["gene_right"] = np.array([g[1] for g in genes], dtype=np.int32)
+    out["gene_strand"] = np.array([g[2] for g in genes], dtype=np.int8)
+    out["gene_score"] = np.array([g[3] for g in genes])
+    out["tabular"] = tab.getvalue()
+    np.savez_compressed(os.path.join(outdir, case + ".npz"), **{k: np.array(v) for k, v in out.items()})
+    print(
+        "%-22s L=%-7d orfs=%-5d nodes=%-5d edges=%-6d genes=%-4d rounds=%-3d ref get_orfs=%.2fs get_graph=%.2fs"
+        % (case, len(seq), len(ol), len(nodes), len(edges), len(genes), int(out["bf_rounds"]), times[0], times[1])
+    )
+
+
+def synth(seed, L):
+    lib = ctypes.CDLL(os.path.join(HERE, "_synth.so"))
+    lib.phx_synth_contig.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(L)
+    assert lib.phx_synth_contig(seed, L, buf) == 0
+    return buf.raw.decode()
+
+
+def save_fasta_gz(path, name, seq):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write((">%s\n" % name).encode())
+        for i in range(0, len(seq), 70):
+            f.write((seq[i : i + 70] + "\n").encode())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.system("gcc -O2 -shared -fPIC -o %s/_synth.so %s/phanotate_amd/csrc/phx_synth.c -lm" % (HERE, REPO))
+    cases = []
+    # the reference's own test inputs (data files, tests/*.fasta)
+    for fn, nm in (("phiX174.fasta", "phiX174"), ("NC_001416.1.fasta", "NC_001416.1"), ("NC_000866.1.fasta", "NC_000866.1")):
+        name, seq = read_fasta(os.path.join(REF, "tests", fn))
+        cases.append((nm, name, seq, {}))
+    for s in range(5):
+        cases.append(("synth50k_%d" % s, "synth50k_%d" % s, synth(s, 50000), {}))
+    for s in range(100, 104):
+        cases.append(("synth6k_%d" % s, "synth6k_%d" % s, synth(s, 6000), {}))
+    px = cases[0][2]
+    rng = np.random.RandomState(7)
+    cases.append(("edge_upper", "edge_upper", px.upper(), {}))
+    cases.append(("edge_nrun", "edge_nrun", px[:1000] + "n" * 100 + px[1100:], {}))
+    iu = list(px.lower())
+    for p in rng.choice(len(iu), 60, replace=False):
+        iu[p] = "ryswkmbvdh"[rng.randint(10)]
+    cases.append(("edge_iupac", "edge_iupac", "".join(iu), {}))
+    cases.append(("edge_badletter", "edge_badletter", px[:500] + "x" + px[501:], {}))
+    cases.append(("edge_L5", "edge_L5", px[:5], {}))
+    cases.append(("edge_L6", "edge_L6", px[:6], {}))
+    cases.append(("edge_L80", "edge_L80", px[:80], {}))
+    cases.append(("edge_L200", "edge_L200", px[:200], {}))
+    cases.append(("edge_L1000", "edge_L1000", px[1000:2000], {}))
+    lam = cases[1][2]
+    cases.append(("edge_L4001", "edge_L4001", lam[20000:24001], {}))
+    cases.append(("edge_L4002", "edge_L4002", lam[30001:34003], {}))
+    # a long ORF-free stretch (>500 bp) forces the bridge edges of functions.py:320-354
+    gapseq = "".join("tagctaactgattaa"[i % 15] for i in range(900))
+    cases.append(("edge_bridge", "edge_bridge", lam[1000:4000] + gapseq + lam[4000:7000], {}))
+    cases.append(("edge_bridge_left", "edge_bridge_left", gapseq + lam[4000:8000], {}))
+    # non-default flags (file_handling.py:51-53)
+    cases.append(("param_minlen60", "param_minlen60", synth(200, 6000), dict(minlen=60)))
+    cases.append(("param_codons", "param_codons", synth(201, 6000), dict(start_codons="atg:0.7,gtg:0.2,ttg:0.05,ctg:0.05", stop_codons="tag,taa")))
+
+    for nm, name, seq, params in cases:
+        if args.only and nm not in args.only:
+            continue
+        save_fasta_gz(os.path.join(HERE, nm + ".fasta.gz"), name, seq)
+        make_case(nm, name, seq, HERE, **params)
+    os.remove(os.path.join(HERE, "_synth.so"))
+
+
+if __name__ == "__main__":
+    main()
