@@ -1,0 +1,191 @@
+/* phx.h — C-ABI of libphx, the MI355X-native drop-in for PHANOTATE's per-contig hot path.
+ *
+ * What it replaces in the reference (all paths under /root/reference):
+ *   phanotate.py:45      orfs  = functions.get_orfs(locus)        functions.py:143-303
+ *   phanotate.py:49      graph = functions.get_graph(orfs)        functions.py:307-454
+ *   phanotate.py:56-64   fz.empty_graph / fz.add_edge / fz.get_path   (external `fastpathz`)
+ *   phanotate.py:65-76   path -> (start, stop, strand, score) features   locus.py:29-37
+ * The reference has no FFI of its own for this path (it is pure Python plus the fastpathz
+ * CPython module); these entry points are what a ctypes binding in phanotate.py would call —
+ * see INTEGRATION.md for the stub.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no exceptions, no global state.  Every
+ * function returns 0 (PHX_OK) or a negative PHX_E_*.  Per-contig problems (the inputs on which the
+ * reference raises a Python exception) are reported in phx_result.status and never fail the batch.
+ * There is NO CPU execution path in this library: without a usable HIP device phx_create fails with
+ * PHX_E_NODEVICE.
+ *
+ * Threading: one phx_ctx per (host thread, device).  Calls on one ctx must not overlap.
+ */
+#ifndef PHX_H
+#define PHX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHX_VERSION 100 /* 0.1.0 */
+#define PHX_MAX_CODONS 16
+
+/* library-level errors */
+#define PHX_OK 0
+#define PHX_E_ARG (-1)      /* bad argument */
+#define PHX_E_NODEVICE (-10) /* no HIP device / device index out of range */
+#define PHX_E_HIP (-11)      /* a HIP runtime call failed; see phx_last_error() */
+#define PHX_E_NOMEM (-12)
+#define PHX_E_STATE (-13) /* call sequence error (e.g. run before upload) */
+#define PHX_E_PARAM (-14) /* codon tables must be 3 letters of acgt; 1..16 starts/stops; minlen >= 6 */
+
+/* per-contig status (phx_result.status); the reference's behaviour in brackets */
+#define PHX_S_OK 0
+#define PHX_S_BADLETTER (-2) /* letter outside acgtnryswkmbvdh [KeyError, functions.py:20-24] */
+#define PHX_S_TOOSHORT (-3)  /* L < 6 [UnboundLocalError/KeyError in GCframe.get, gc_frame_plot.py:53-69] */
+#define PHX_S_PARALLEL (-6)  /* a bridge edge duplicates a connect edge [ValueError, graphs.py:74] */
+#define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit) */
+#define PHX_S_NEGCYCLE (-9)  /* relaxation did not converge in V rounds */
+#define PHX_S_NOPATH 1       /* warning: target unreachable from source; 0 genes reported */
+
+typedef struct phx_ctx phx_ctx;
+
+/* Flags of the reference CLI that reach the path (file_handling.py:51-66, phanotate.py:42-44). */
+typedef struct phx_params {
+    int32_t minlen;                        /* -l/--minlen, default 90 */
+    int32_t n_start;                       /* -s/--start_codons */
+    char start[PHX_MAX_CODONS][4];         /* lower-case, NUL-terminated */
+    double start_w[PHX_MAX_CODONS];        /* weight / max(weight), file_handling.py:58-62 */
+    int32_t n_stop;                        /* -e/--stop_codons */
+    char stop[PHX_MAX_CODONS][4];
+} phx_params;
+
+/* One called gene = one ORF edge on the shortest path (phanotate.py:71-76, locus.py:29-37).
+ * left/right are 1-based inclusive coordinates, left < right on both strands; the tabular writer
+ * (locus.py:39-56) prints left,right for '+' and right,left for '-'. */
+typedef struct phx_gene {
+    int32_t left;
+    int32_t right;
+    int32_t strand; /* +1 / -1 */
+    int32_t frame;  /* reference Node.frame of the ORF: +-1..3 */
+    double score;   /* ORF edge weight, what the reference prints with '%E' */
+} phx_gene;
+
+typedef struct phx_result {
+    int32_t status;  /* PHX_S_* */
+    int32_t n_genes;
+    phx_gene *genes; /* library-owned; in path order == ascending left coordinate */
+} phx_result;
+
+/* ---- stage-tap records (parity tests; layout is part of the ABI) ---- */
+typedef struct phx_orf {
+    int32_t start; /* Orf.start (1-based; fwd: first base of the start codon, rev: leftmost base of its reverse complement) */
+    int32_t stop;  /* Orf.stop  (dict key: fwd first base of the stop codon, rev leftmost base of the rc stop codon / 1,2,3) */
+    int32_t frame; /* +-1..3 */
+    int32_t length;
+    int32_t rbs;      /* score_rbs bin 0..27 */
+    int32_t startidx; /* index into params.start of Orf.start_codon(), or -1 */
+    int32_t group;    /* stop-group rank in reference insertion order */
+    int32_t hist[9];  /* GC-frame class counts, (max_idx-1)*3 + (min_idx-1) */
+    double pstop;
+    double weight_rbs;
+    double S; /* sum over sense codons of pos_max[max_idx]*pos_min[min_idx] */
+    double weight;
+} phx_orf;
+
+typedef struct phx_node {
+    int32_t pos;
+    int8_t type;  /* 0 start, 1 stop, 2 source, 3 target */
+    int8_t frame; /* +-1..3, 0 for source/target */
+    int16_t pad;
+    int32_t other; /* Orfs.other_end[pos] as seen by get_graph (functions.py:363,369); -1 for source/target */
+    int32_t refidx; /* rank of this node in the reference's Graph.iternodes() order */
+    double o;      /* the o1/o2 term of functions.py:373-384 for this position */
+} phx_node;
+
+typedef struct phx_edge { /* in-edge list order of the device graph: grouped by dst */
+    int32_t src, dst;     /* device node ids (position-sorted; source = V-2, target = V-1) */
+    double w;             /* Decimal weight of the reference, in fp64 */
+} phx_edge;
+
+typedef struct phx_globals {
+    int64_t L;
+    double pstop;               /* functions.py:178, also pgap (functions.py:309) */
+    double background_rbs[28];  /* functions.py:180-181, normalised */
+    double training_rbs[28];    /* functions.py:254-255, normalised */
+    double pos_max[4], pos_min[4]; /* functions.py:281-284 */
+    int32_t n_orf, n_group, n_node, n_edge, n_bridge;
+    int32_t n_limbs;     /* 64-bit limbs of the integer kernel that solved this batch */
+    int32_t sssp_sweeps; /* outer sweeps of the device relaxation */
+    int32_t status;
+} phx_globals;
+
+/* ---- library ---- */
+int phx_version(void);
+int phx_device_count(void);
+const char *phx_strerror(int code);
+/* Text of the last failing HIP call on this ctx (or on the last failed phx_create when ctx==NULL). */
+const char *phx_last_error(const phx_ctx *ctx);
+
+/* Fills *p with the reference defaults: atg:0.85,gtg:0.10,ttg:0.05 / tag,tga,taa / minlen 90. */
+void phx_default_params(phx_params *p);
+
+/* device: HIP ordinal.  stream: a hipStream_t the caller owns (e.g. torch's current stream), or
+ * NULL to let the ctx create its own.  All kernels and copies of this ctx are issued on it. */
+int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out);
+void phx_destroy(phx_ctx *ctx);
+
+/* ---- the whole path, batched (replaces phanotate.py:40-76 for n contigs) ---- */
+/* seq[i]: ASCII, any case, len[i] characters, not NUL-terminated; borrowed for the call. */
+int phx_annotate(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *len, phx_result *out /* [n] */);
+void phx_free_results(phx_result *res, int32_t n);
+
+/* The same in three steps, so a caller can keep inputs resident in HBM and time phx_run alone. */
+int phx_upload(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *len); /* H2D of ASCII */
+/* Alternative to phx_upload: the concatenated ASCII is already in device memory (offsets on host, n+1 entries). */
+int phx_attach(phx_ctx *ctx, int32_t n, const void *d_ascii, const int64_t *offsets);
+int phx_run(phx_ctx *ctx);                        /* every kernel of the path; blocks until results are in HBM */
+int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] */
+
+/* ---- stage taps on the batch last processed by phx_run (parity tests) ---- */
+int phx_tap_globals(phx_ctx *ctx, int32_t contig, phx_globals *out);
+/* per 0-based position, each array L bytes (any may be NULL):
+ *   cls  bits0-2 codon class at p (0 none,1 fwd start,2 rev start,3 fwd stop,4 rev stop; elif order of functions.py:198-215)
+ *   gcc  low nibble fwd (max_idx-1)*3+(min_idx-1) of gc_pos_freq[p+1], high nibble the reversed triple
+ *   binF/binR  score_rbs of dna[p-20:p+1] / rev_comp(dna[p:p+21]) */
+int phx_tap_positions(phx_ctx *ctx, int32_t contig, uint8_t *cls, uint8_t *gcc, uint8_t *binF, uint8_t *binR);
+int phx_tap_orfs(phx_ctx *ctx, int32_t contig, phx_orf *out /* [n_orf], reference iter_orfs order */);
+int phx_tap_nodes(phx_ctx *ctx, int32_t contig, phx_node *out /* [n_node], device order */);
+int phx_tap_edges(phx_ctx *ctx, int32_t contig, phx_edge *out /* [n_edge] */);
+/* path as device node ids, source first; dist_limbs receives n_limbs 64-bit words (two's complement) */
+int phx_tap_path(phx_ctx *ctx, int32_t contig, int32_t *path, int32_t cap, int32_t *n_path, uint64_t *dist_limbs, int32_t cap_limbs);
+
+/* ---- the solver alone (the fastpathz boundary, phanotate.py:56-64) ----
+ * Edges (src[i] -> dst[i]) over nodes 0..V-1 with integer weights given as n_limbs little-endian
+ * 64-bit words each (two's complement).  Writes the node ids of the shortest path source..target to
+ * path_out (cap entries) and its length to *n_path (0 if unreachable). */
+int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs,
+              int32_t n_limbs, int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path,
+              uint64_t *dist_limbs);
+
+/* ---- measurement ---- */
+#define PHX_N_STAGES 12
+/* When on, every kernel launch of phx_run is bracketed by hipEvents on the ctx stream. */
+int phx_set_profiling(phx_ctx *ctx, int on);
+/* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k). */
+int phx_get_stage_ms(phx_ctx *ctx, float *ms /* [PHX_N_STAGES] */, int32_t *launches /* [PHX_N_STAGES] */, int reset);
+const char *phx_stage_name(int k);
+/* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
+int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
+
+/* ---- host utilities (no device needed) ---- */
+/* Deterministic synthetic phage-like contig: exactly L lower-case acgt chars. */
+int phx_synth_contig(uint64_t seed, int64_t L, char *out);
+/* The 4096-entry leftward-6-mer RBS score table the position kernel uses (4 offset classes packed
+ * in one uint32, class A=offsets 3-4 in bits 0-7, B=5-10, C=11-12, D=13-15); for CPU-side tests. */
+int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t *t4 /* [256] */, uint32_t *t3 /* [64] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHX_H */

@@ -1,0 +1,204 @@
+"""Host-side front end of libphx: parameter handling, batching, result unpacking.
+
+Mirrors the way phanotate.py drives the path (phanotate.py:40-76): per contig
+get_orfs -> get_graph -> shortest path -> features; here a whole batch of contigs goes
+through the HIP kernels at once.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PhxError
+
+
+def make_params(start_codons="atg:0.85,gtg:0.10,ttg:0.05", stop_codons="tag,tga,taa", minlen=90):
+    """Same flag syntax and normalisation as file_handling.get_args (file_handling.py:51-66)."""
+    p = _lib.Params()
+    p.minlen = int(minlen)
+    pairs = [tuple(x.split(":")) for x in start_codons.split(",")]
+    seen = {}
+    for codon, w in pairs:  # dict semantics: a repeated codon keeps its first position, last weight
+        seen[codon.lower()] = float(w)
+    m = max(seen.values())
+    if len(seen) > _lib.MAXC:
+        raise ValueError("at most %d start codons" % _lib.MAXC)
+    p.n_start = len(seen)
+    for i, (codon, w) in enumerate(seen.items()):
+        p.start[i].value = codon.encode()
+        p.start_w[i] = w / m
+    stops = [c.lower() for c in stop_codons.split(",")]
+    if len(stops) > _lib.MAXC:
+        raise ValueError("at most %d stop codons" % _lib.MAXC)
+    p.n_stop = len(stops)
+    for i, c in enumerate(stops):
+        p.stop[i].value = c.encode()
+    return p
+
+
+def synth_contig(seed, L=50000):
+    """Deterministic synthetic phage-like contig (host utility of libphx)."""
+    buf = C.create_string_buffer(int(L))
+    rc = _lib.lib().phx_synth_contig(int(seed), int(L), buf)
+    if rc:
+        raise PhxError(rc, "phx_synth_contig")
+    return buf.raw
+
+
+class Annotator:
+    """One libphx context = one (host thread, GPU).  `stream` is a raw hipStream_t (int) or None."""
+
+    def __init__(self, params=None, device=0, stream=None):
+        self.L = _lib.lib()
+        self.params = params or make_params()
+        h = C.c_void_p()
+        rc = self.L.phx_create(C.byref(self.params), int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            raise PhxError(rc, "%s (%s)" % (self.L.phx_strerror(rc).decode(), self.L.phx_last_error(None).decode()))
+        self.h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.phx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise PhxError(rc, "%s: %s (%s)" % (what, self.L.phx_strerror(rc).decode(), self.L.phx_last_error(self.h).decode()))
+
+    # ---- the path ----
+    def upload(self, seqs):
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*seqs)
+        lens = (C.c_int64 * n)(*[len(s) for s in seqs])
+        self._keep = (seqs, arr, lens)
+        self._chk(self.L.phx_upload(self.h, n, arr, lens), "phx_upload")
+        self.n = n
+
+    def attach(self, dev_ptr, offsets):
+        """Concatenated ASCII already in HBM (e.g. a torch uint8 tensor's data_ptr()); offsets has n+1 entries."""
+        offs = (C.c_int64 * len(offsets))(*[int(x) for x in offsets])
+        self._keep = (offs,)
+        self._chk(self.L.phx_attach(self.h, len(offsets) - 1, C.c_void_p(int(dev_ptr)), offs), "phx_attach")
+        self.n = len(offsets) - 1
+
+    def run(self):
+        self._chk(self.L.phx_run(self.h), "phx_run")
+
+    def download(self):
+        res = (_lib.Result * max(self.n, 1))()
+        self._chk(self.L.phx_download(self.h, res), "phx_download")
+        out = []
+        for i in range(self.n):
+            r = res[i]
+            if r.n_genes:
+                raw = np.ctypeslib.as_array(C.cast(r.genes, C.POINTER(C.c_uint8)), (r.n_genes * _lib.GENE_DT.itemsize,))
+                genes = raw.view(_lib.GENE_DT).copy()
+            else:
+                genes = np.zeros(0, _lib.GENE_DT)
+            out.append((int(r.status), genes))
+        self.L.phx_free_results(res, self.n)
+        return out
+
+    def annotate(self, seqs):
+        """[(status, genes structured array)] for every contig, in input order."""
+        self.upload(seqs)
+        self.run()
+        return self.download()
+
+    # ---- stage taps (parity tests) ----
+    def globals(self, i):
+        g = _lib.Globals()
+        self._chk(self.L.phx_tap_globals(self.h, i, C.byref(g)), "phx_tap_globals")
+        return g
+
+    def positions(self, i):
+        L = int(self.globals(i).L)
+        a = [np.zeros(L, np.uint8) for _ in range(4)]
+        self._chk(self.L.phx_tap_positions(self.h, i, *[x.ctypes.data_as(C.c_void_p) for x in a]), "phx_tap_positions")
+        return dict(cls=a[0], gcc=a[1], binF=a[2], binR=a[3])
+
+    def orfs(self, i):
+        g = self.globals(i)
+        a = np.zeros(max(g.n_orf, 0), _lib.ORF_DT)
+        self._chk(self.L.phx_tap_orfs(self.h, i, a.ctypes.data_as(C.c_void_p)), "phx_tap_orfs")
+        return a
+
+    def nodes(self, i):
+        g = self.globals(i)
+        a = np.zeros(max(g.n_node, 0), _lib.NODE_DT)
+        self._chk(self.L.phx_tap_nodes(self.h, i, a.ctypes.data_as(C.c_void_p)), "phx_tap_nodes")
+        return a
+
+    def edges(self, i):
+        g = self.globals(i)
+        a = np.zeros(max(g.n_edge, 0), _lib.EDGE_DT)
+        self._chk(self.L.phx_tap_edges(self.h, i, a.ctypes.data_as(C.c_void_p)), "phx_tap_edges")
+        return a
+
+    def path(self, i):
+        g = self.globals(i)
+        p = np.zeros(max(g.n_node, 1), np.int32)
+        n = C.c_int32()
+        limbs = np.zeros(32, np.uint64)
+        self._chk(self.L.phx_tap_path(self.h, i, p.ctypes.data_as(C.c_void_p), len(p), C.byref(n), limbs.ctypes.data_as(C.c_void_p), 32), "phx_tap_path")
+        nl = max(g.n_limbs, 1)
+        v = 0
+        for k in range(nl):
+            v |= int(limbs[k]) << (64 * k)
+        if v >> (64 * nl - 1):
+            v -= 1 << (64 * nl)
+        return p[: n.value].copy(), v
+
+    # ---- solver alone (fastpathz boundary) ----
+    def solve(self, V, src, dst, weights, source, target, n_limbs=None):
+        """Exact shortest path over integer weights (python ints).  Returns (path node ids, distance) or ([], None)."""
+        E = len(src)
+        mx = max([abs(int(w)) for w in weights] + [1])
+        bits = mx.bit_length() + max(V, 2).bit_length() + 3
+        if n_limbs is None:
+            n_limbs = 2 if bits <= 128 else 4 if bits <= 256 else 8 if bits <= 512 else 17
+        wl = np.zeros((max(E, 1), n_limbs), np.uint64)
+        mask = (1 << 64) - 1
+        for e, w in enumerate(weights):
+            w = int(w) & ((1 << (64 * n_limbs)) - 1)
+            for k in range(n_limbs):
+                wl[e, k] = (w >> (64 * k)) & mask
+        s = np.ascontiguousarray(src, np.int32)
+        d = np.ascontiguousarray(dst, np.int32)
+        path = np.zeros(V, np.int32)
+        n = C.c_int32()
+        dl = np.zeros(n_limbs, np.uint64)
+        self._chk(self.L.phx_solve(self.h, V, E, s.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), wl.ctypes.data_as(C.c_void_p),
+                                   n_limbs, source, target, path.ctypes.data_as(C.c_void_p), V, C.byref(n), dl.ctypes.data_as(C.c_void_p)), "phx_solve")
+        if n.value == 0:
+            return [], None
+        v = 0
+        for k in range(n_limbs):
+            v |= int(dl[k]) << (64 * k)
+        if v >> (64 * n_limbs - 1):
+            v -= 1 << (64 * n_limbs)
+        return path[: n.value].tolist(), v
+
+    # ---- measurement ----
+    def set_profiling(self, on=True):
+        self._chk(self.L.phx_set_profiling(self.h, 1 if on else 0), "phx_set_profiling")
+
+    def stage_ms(self, reset=True):
+        ms = (C.c_float * _lib.N_STAGES)()
+        nl = (C.c_int32 * _lib.N_STAGES)()
+        self._chk(self.L.phx_get_stage_ms(self.h, ms, nl, 1 if reset else 0), "phx_get_stage_ms")
+        return {self.L.phx_stage_name(k).decode(): (float(ms[k]), int(nl[k])) for k in range(_lib.N_STAGES)}
+
+    def batch_sizes(self):
+        v = [C.c_int64() for _ in range(4)]
+        self._chk(self.L.phx_batch_sizes(self.h, *[C.byref(x) for x in v]), "phx_batch_sizes")
+        return dict(L=v[0].value, n_orf=v[1].value, n_node=v[2].value, n_edge=v[3].value)

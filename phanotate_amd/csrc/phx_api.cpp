@@ -1,0 +1,783 @@
+// phx_api.cpp — C-ABI of libphx (include/phx.h): context, HBM buffers, kernel orchestration, taps.
+//
+// There is deliberately no CPU implementation of the path in this file: if HIP is unusable every
+// entry point that would compute returns PHX_E_NODEVICE / PHX_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "phx_internal.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_PATH, ST_COPY };
+const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "path", "copies"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct phx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    phx_params params;
+    std::string err;
+    // device constants
+    DParams *d_params = nullptr;
+    uint32_t *d_t6 = nullptr, *d_t5 = nullptr, *d_t4 = nullptr, *d_t3 = nullptr;
+    // batch
+    int n = 0;
+    bool uploaded = false, ran = false;
+    int64_t totalL = 0, tot_orf = 0, tot_grp = 0, tot_node = 0, tot_edge = 0;
+    int n_limbs = 0;
+    std::vector<DMeta> meta;
+    std::vector<DTile> tiles;
+    const void *attached = nullptr;
+    // buffers
+    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_gcc, b_cnt, b_cov, b_rbs, b_linkF, b_linkR, b_orf, b_grp;
+    DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot;
+    void *h_stage = nullptr; // pinned staging for H2D of ASCII
+    size_t h_stage_cap = 0;
+    std::vector<DGene> h_genes;
+    // profiling
+    bool prof = false;
+    float stage_ms[PHX_N_STAGES] = {0};
+    int stage_n[PHX_N_STAGES] = {0};
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+            return PHX_E_HIP;                                                                                  \
+        }                                                                                                      \
+    } while (0)
+
+int ensure(phx_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return PHX_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return PHX_OK;
+}
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+// ---- RBS motif tables: score_rbs (functions.py:48-138) as "max over matching (motif, offset class)" ----
+struct RbsRule { int score; const char *motif; int cls; }; // cls: 0 = offsets 3-4, 1 = 5-10, 2 = 11-12, 3 = 13-15
+const RbsRule kRules[] = {
+    {27, "ggagga", 1}, {26, "ggagga", 0}, {25, "ggagga", 2}, {24, "ggagg", 1}, {23, "ggagg", 0}, {22, "gagga", 1}, {21, "gagga", 0},
+    {20, "gagga", 2}, {20, "ggagg", 2},
+    {19, "ggacga", 1}, {19, "ggatga", 1}, {19, "ggaaga", 1}, {19, "ggcgga", 1}, {19, "ggggga", 1}, {19, "ggtgga", 1},
+    {18, "ggaaga", 0}, {18, "ggatga", 0}, {18, "ggacga", 0}, {18, "ggtgga", 0}, {18, "ggggga", 0}, {18, "ggcgga", 0},
+    {17, "ggaaga", 2}, {17, "ggatga", 2}, {17, "ggacga", 2}, {17, "ggtgga", 2}, {17, "ggggga", 2}, {17, "ggcgga", 2},
+    {16, "ggag", 1}, {16, "gagg", 1}, {15, "agga", 1}, {14, "ggtgg", 1}, {14, "ggggg", 1}, {14, "ggcgg", 1},
+    {13, "agg", 1}, {13, "gag", 1}, {13, "gga", 1},
+    {12, "agga", 2}, {12, "gagg", 2}, {12, "ggag", 2}, {11, "agga", 0}, {11, "gagg", 0}, {11, "ggag", 0},
+    {10, "gagga", 3}, {10, "ggagg", 3}, {10, "ggagga", 3},
+    {9, "gaaga", 1}, {9, "gatga", 1}, {9, "gacga", 1}, {8, "ggtgg", 0}, {8, "ggggg", 0}, {8, "ggcgg", 0},
+    {7, "ggtgg", 2}, {7, "ggggg", 2}, {7, "ggcgg", 2}, {6, "agg", 2}, {6, "gag", 2}, {6, "gga", 2},
+    {5, "gaaga", 0}, {5, "gatga", 0}, {5, "gacga", 0}, {4, "gaaga", 2}, {4, "gatga", 2}, {4, "gacga", 2},
+    {3, "agga", 3}, {3, "gagg", 3}, {3, "ggag", 3}, {2, "agg", 3}, {2, "gag", 3}, {2, "gga", 3},
+    {2, "ggaaga", 3}, {2, "ggatga", 3}, {2, "ggacga", 3}, {2, "ggtgg", 3}, {2, "ggggg", 3}, {2, "ggcgg", 3},
+    {1, "agg", 0}, {1, "gag", 0}, {1, "gga", 0},
+};
+inline int code_of(char c) { return c == 'a' ? 0 : c == 'c' ? 1 : c == 't' ? 2 : c == 'g' ? 3 : -1; }
+
+// table for k-mers of which the first `len` symbols are usable (symbol j at bits 2j..2j+1)
+void build_rbs_table(int len, uint32_t *out) {
+    const int n = 1 << (2 * len);
+    for (int code = 0; code < n; code++) {
+        uint32_t best[4] = {0, 0, 0, 0};
+        for (const RbsRule &r : kRules) {
+            const int m = (int)strlen(r.motif);
+            if (m > len) continue;
+            bool ok = true;
+            for (int j = 0; j < m && ok; j++) ok = ((code >> (2 * j)) & 3) == code_of(r.motif[j]);
+            if (ok && (uint32_t)r.score > best[r.cls]) best[r.cls] = (uint32_t)r.score;
+        }
+        out[code] = best[0] | (best[1] << 8) | (best[2] << 16) | (best[3] << 24);
+    }
+}
+
+int check_params(const phx_params *p) {
+    if (!p || p->minlen < 6 || p->n_start < 1 || p->n_start > PHX_MAX_CODONS || p->n_stop < 1 || p->n_stop > PHX_MAX_CODONS) return PHX_E_PARAM;
+    for (int i = 0; i < p->n_start; i++) {
+        for (int j = 0; j < 3; j++) if (code_of(p->start[i][j]) < 0) return PHX_E_PARAM;
+        if (!(p->start_w[i] == p->start_w[i])) return PHX_E_PARAM;
+    }
+    for (int i = 0; i < p->n_stop; i++)
+        for (int j = 0; j < 3; j++) if (code_of(p->stop[i][j]) < 0) return PHX_E_PARAM;
+    return PHX_OK;
+}
+
+void build_dparams(const phx_params *p, DParams *d) {
+    memset(d, 0, sizeof(*d));
+    d->minlen = p->minlen;
+    d->n_start = p->n_start;
+    for (int i = 0; i < p->n_start; i++) d->start_w[i] = p->start_w[i];
+    auto codon_code = [](const char *c) { return code_of(c[0]) | (code_of(c[1]) << 2) | (code_of(c[2]) << 4); };
+    auto rc_code = [](int ci) { // reverse complement of a codon code
+        int c0 = ci & 3, c1 = (ci >> 2) & 3, c2 = (ci >> 4) & 3;
+        return (c2 ^ 2) | ((c1 ^ 2) << 2) | ((c0 ^ 2) << 4);
+    };
+    int start_idx[64], stop_is[64];
+    for (int i = 0; i < 64; i++) { start_idx[i] = -1; stop_is[i] = 0; }
+    for (int i = p->n_start - 1; i >= 0; i--) start_idx[codon_code(p->start[i])] = i; // first occurrence wins, like dict lookup of the codon
+    for (int i = 0; i < p->n_stop; i++) stop_is[codon_code(p->stop[i])] = 1;
+    const int atg = codon_code("atg"), cat = codon_code("cat");
+    for (int ci = 0; ci < 64; ci++) {
+        const int rc = rc_code(ci);
+        int cls = CLS_NONE, idx = 0;
+        if (start_idx[ci] >= 0) { cls = CLS_FS; idx = start_idx[ci]; }      // functions.py:198
+        else if (start_idx[rc] >= 0) { cls = CLS_RS; idx = start_idx[rc]; } // functions.py:200
+        else if (stop_is[ci]) cls = CLS_FT;                                 // functions.py:202
+        else if (stop_is[rc]) cls = CLS_RT;                                 // functions.py:215
+        d->cls_tab[ci] = (uint8_t)(cls | (idx << 3) | (start_idx[rc] >= 0 ? 0x80 : 0));
+        d->atg_tab[ci] = (uint8_t)((ci == atg ? 1 : 0) | (ci == cat ? 2 : 0));
+    }
+}
+
+// ---- profiling helpers ----
+hipEvent_t get_event(phx_ctx *c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct StageTimer {
+    phx_ctx *c; int st; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(phx_ctx *c_, int st_) : c(c_), st(st_) {
+        if (c->prof) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~StageTimer() {
+        if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back({st, {a, b}}); }
+    }
+};
+void collect_timers(phx_ctx *c) {
+    for (auto &p : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) { c->stage_ms[p.first] += ms; c->stage_n[p.first]++; }
+        c->ev_pool.push_back(p.second.first);
+        c->ev_pool.push_back(p.second.second);
+    }
+    c->pending.clear();
+}
+
+void fill_batch(phx_ctx *c, DBatch *b) {
+    memset(b, 0, sizeof(*b));
+    b->n_contig = c->n;
+    b->meta = (DMeta *)c->b_meta.p;
+    b->params = c->d_params;
+    b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
+    b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
+    b->cls = (uint8_t *)c->b_cls.p; b->gcc = (uint8_t *)c->b_gcc.p; b->cnt = (uint8_t *)c->b_cnt.p; b->cov = (uint8_t *)c->b_cov.p;
+    b->rbs = (uint16_t *)c->b_rbs.p;
+    b->linkF = (uint32_t *)c->b_linkF.p; b->linkR = (uint32_t *)c->b_linkR.p;
+    b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
+    b->npos = (int32_t *)c->b_npos.p; b->ninfo = (int32_t *)c->b_ninfo.p; b->nother = (int32_t *)c->b_nother.p; b->parent = (int32_t *)c->b_parent.p;
+    b->nlink = (uint32_t *)c->b_nlink.p; b->in_off = (uint32_t *)c->b_inoff.p;
+    b->no = (double *)c->b_no.p;
+    b->dist = (uint64_t *)c->b_dist.p;
+    b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
+    b->path = (int32_t *)c->b_path.p;
+    b->genes = (DGene *)c->b_genes.p;
+    b->gene_total = (uint32_t *)c->b_gtot.p;
+}
+
+int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
+    if (n < 0) return PHX_E_ARG;
+    c->n = n;
+    c->meta.assign((size_t)n, DMeta());
+    c->tiles.clear();
+    int64_t off = 0;
+    for (int i = 0; i < n; i++) {
+        int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
+        if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
+        DMeta &m = c->meta[(size_t)i];
+        memset(&m, 0, sizeof(m));
+        m.off = offsets_or_null ? offsets_or_null[i] : off;
+        m.L = (int32_t)L;
+        for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) c->tiles.push_back(DTile{i, (int32_t)p0});
+        off += L;
+    }
+    c->totalL = offsets_or_null ? offsets_or_null[n] : off;
+    c->uploaded = true;
+    c->ran = false;
+    return PHX_OK;
+}
+
+int ensure_position_buffers(phx_ctx *c) {
+    const size_t T = (size_t)c->totalL + 64;
+    int rc;
+    if ((rc = ensure(c, c->b_cls, T))) return rc;
+    if ((rc = ensure(c, c->b_gcc, T))) return rc;
+    if ((rc = ensure(c, c->b_cnt, T))) return rc;
+    if ((rc = ensure(c, c->b_cov, T))) return rc;
+    if ((rc = ensure(c, c->b_rbs, T * 2))) return rc;
+    if ((rc = ensure(c, c->b_linkF, T * 4))) return rc;
+    if ((rc = ensure(c, c->b_linkR, T * 4))) return rc;
+    if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
+    if ((rc = ensure(c, c->b_gtot, 64))) return rc;
+    return PHX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int phx_version(void) { return PHX_VERSION; }
+
+int phx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *phx_strerror(int code) {
+    switch (code) {
+    case PHX_OK: return "ok";
+    case PHX_E_ARG: return "bad argument";
+    case PHX_E_NODEVICE: return "no usable HIP device (libphx has no CPU path)";
+    case PHX_E_HIP: return "HIP runtime error";
+    case PHX_E_NOMEM: return "out of memory";
+    case PHX_E_STATE: return "call sequence error";
+    case PHX_E_PARAM: return "bad codon table / minlen";
+    case PHX_S_BADLETTER: return "letter outside the IUPAC nucleotide alphabet";
+    case PHX_S_TOOSHORT: return "contig shorter than 6 bases";
+    case PHX_S_PARALLEL: return "bridge edge duplicates a connect edge";
+    case PHX_S_OVERFLOW: return "integer path sums overflow";
+    case PHX_S_NEGCYCLE: return "relaxation did not converge";
+    case PHX_S_NOPATH: return "target unreachable";
+    default: return "unknown";
+    }
+}
+
+const char *phx_last_error(const phx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void phx_default_params(phx_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->minlen = 90;
+    p->n_start = 3;
+    strcpy(p->start[0], "atg"); strcpy(p->start[1], "gtg"); strcpy(p->start[2], "ttg");
+    // file_handling.py:58-62: weights divided by their maximum
+    p->start_w[0] = 0.85 / 0.85; p->start_w[1] = 0.10 / 0.85; p->start_w[2] = 0.05 / 0.85;
+    p->n_stop = 3;
+    strcpy(p->stop[0], "tag"); strcpy(p->stop[1], "tga"); strcpy(p->stop[2], "taa");
+}
+
+int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
+    if (t6) build_rbs_table(6, t6);
+    if (t5) build_rbs_table(5, t5);
+    if (t4) build_rbs_table(4, t4);
+    if (t3) build_rbs_table(3, t3);
+    return PHX_OK;
+}
+
+int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) {
+    if (!out) return PHX_E_ARG;
+    *out = nullptr;
+    int rc = check_params(params);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_create_error = e != hipSuccess ? hipGetErrorString(e) : "device index out of range";
+        return PHX_E_NODEVICE;
+    }
+    phx_ctx *c = new phx_ctx();
+    c->device = device;
+    c->params = *params;
+    auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
+    if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
+        c->own_stream = true;
+    }
+    DParams dp;
+    build_dparams(params, &dp);
+    std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
+    phx_rbs_table(t6.data(), t5.data(), t4.data(), t3.data());
+    if (hipMalloc((void **)&c->d_params, sizeof(DParams)) != hipSuccess || hipMalloc((void **)&c->d_t6, 4096 * 4) != hipSuccess ||
+        hipMalloc((void **)&c->d_t5, 1024 * 4) != hipSuccess || hipMalloc((void **)&c->d_t4, 256 * 4) != hipSuccess ||
+        hipMalloc((void **)&c->d_t3, 64 * 4) != hipSuccess) { c->err = "hipMalloc failed"; return fail(PHX_E_NOMEM); }
+    if (hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t6, t6.data(), 4096 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_t5, t5.data(), 1024 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t4, t4.data(), 256 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_t3, t3.data(), 64 * 4, hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(PHX_E_HIP); }
+    *out = c;
+    return PHX_OK;
+}
+
+void phx_destroy(phx_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_gcc, &c->b_cnt, &c->b_cov, &c->b_rbs, &c->b_linkF, &c->b_linkR, &c->b_orf, &c->b_grp,
+                     &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot};
+    for (DevBuf *b : all) release(*b);
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_t6) (void)hipFree(c->d_t6);
+    if (c->d_t5) (void)hipFree(c->d_t5);
+    if (c->d_t4) (void)hipFree(c->d_t4);
+    if (c->d_t3) (void)hipFree(c->d_t3);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    collect_timers(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len) {
+    if (!c || n < 0 || (n > 0 && (!seq || !len))) return PHX_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->attached = nullptr;
+    int rc = set_batch_layout(c, n, len, nullptr);
+    if (rc) return rc;
+    const size_t T = (size_t)c->totalL + 64;
+    if ((rc = ensure(c, c->b_ascii, T))) return rc;
+    if (c->h_stage_cap < T) {
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_stage, T + T / 8, hipHostMallocDefault));
+        c->h_stage_cap = T + T / 8;
+    }
+    for (int i = 0; i < n; i++) memcpy((char *)c->h_stage + c->meta[(size_t)i].off, seq[i], (size_t)len[i]);
+    StageTimer t(c, ST_COPY);
+    HIPCHK(c, hipMemcpyAsync(c->b_ascii.p, c->h_stage, (size_t)c->totalL, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHX_OK;
+}
+
+int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offsets) {
+    if (!c || n < 0 || !offsets || (n > 0 && !d_ascii)) return PHX_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_batch_layout(c, n, nullptr, offsets);
+    if (rc) return rc;
+    c->attached = d_ascii;
+    return PHX_OK;
+}
+
+int phx_run(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (!c->uploaded) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const int n = c->n;
+    c->ran = false;
+    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
+    if (n == 0) { c->ran = true; return PHX_OK; }
+    if ((rc = ensure_position_buffers(c))) return rc;
+    hipStream_t s = c->stream;
+    const size_t T = (size_t)c->totalL;
+    // reset per-contig accumulators (offsets and lengths stay)
+    for (DMeta &m : c->meta) { int64_t off = m.off; int32_t L = m.L; memset(&m, 0, sizeof(m)); m.off = off; m.L = L; }
+    DBatch b;
+    {
+        StageTimer t(c, ST_MEMSET);
+        HIPCHK(c, hipMemsetAsync(c->b_linkF.p, 0, T * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_linkR.p, 0, T * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->b_cov.p, 0, T, s));
+        HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
+    }
+    {
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));
+    }
+    fill_batch(c, &b);
+    { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
+    { StageTimer t(c, ST_ORF_COUNT); phxk_orf_count(&b, s); }
+    HIPCHK(c, hipGetLastError());
+    { // sync #1: ORF / group counts -> offsets
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    int64_t o = 0, g = 0, v = 0;
+    for (DMeta &m : c->meta) {
+        m.orf_off = o; m.grp_off = g; m.node_off = v;
+        m.n_node = m.status < 0 ? 0 : m.n_orf + m.n_grp + 2;
+        o += m.n_orf; g += m.n_grp; v += m.n_node;
+    }
+    c->tot_orf = o; c->tot_grp = g; c->tot_node = v;
+    if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(o + 1)))) return rc;
+    if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * (size_t)(g + 1)))) return rc;
+    const size_t NV = (size_t)v + 8;
+    if ((rc = ensure(c, c->b_npos, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_ninfo, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_nother, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_parent, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_nlink, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
+    if ((rc = ensure(c, c->b_path, NV * 4))) return rc;
+    if ((rc = ensure(c, c->b_genes, sizeof(DGene) * (size_t)(g + 1)))) return rc;
+    {
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    fill_batch(c, &b);
+    { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
+    { StageTimer t(c, ST_ORF_STATS); phxk_orf_stats(&b, s); }
+    { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
+    { StageTimer t(c, ST_NODES); phxk_nodes(&b, s); }
+    { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); }
+    HIPCHK(c, hipGetLastError());
+    { // sync #2: edge counts, weight magnitudes
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    int64_t e = 0;
+    int need_bits = 0;
+    for (DMeta &m : c->meta) {
+        m.edge_off = e;
+        if (m.status < 0) { m.n_edge = 0; continue; }
+        e += m.n_edge;
+        // |dist| <= V * max|w|: bits = maxexp + ceil(log2 V) + sign + one spare bit below the INF pattern
+        int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
+        need_bits = std::max(need_bits, bits);
+    }
+    c->tot_edge = e;
+    int nl = need_bits <= 128 ? 2 : need_bits <= 256 ? 4 : need_bits <= 512 ? 8 : 17;
+    if (need_bits > 17 * 64) {
+        for (DMeta &m : c->meta) {
+            int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
+            if (m.status >= 0 && bits > 17 * 64) m.status = PHX_S_OVERFLOW;
+        }
+    }
+    c->n_limbs = nl;
+    if ((rc = ensure(c, c->b_esrc, (size_t)(e + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_ew, (size_t)(e + 1) * 8))) return rc;
+    if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)nl))) return rc;
+    {
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    fill_batch(c, &b);
+    { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+    { StageTimer t(c, ST_SSSP); phxk_sssp(&b, nl, s); }
+    { StageTimer t(c, ST_PATH); phxk_path(&b, nl, s); }
+    HIPCHK(c, hipGetLastError());
+    { // sync #3: statuses, gene counts
+        StageTimer t(c, ST_COPY);
+        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    collect_timers(c);
+    c->ran = true;
+    return PHX_OK;
+}
+
+int phx_download(phx_ctx *c, phx_result *out) {
+    if (!c || (!out && c->n > 0)) return PHX_E_ARG;
+    if (!c->ran) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t total = 0;
+    for (const DMeta &m : c->meta) total = std::max<int64_t>(total, m.gene_off + m.n_genes);
+    c->h_genes.resize((size_t)total);
+    if (total) {
+        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), c->b_genes.p, sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < c->n; i++) {
+        const DMeta &m = c->meta[(size_t)i];
+        out[i].status = m.status;
+        out[i].n_genes = m.status < 0 ? 0 : m.n_genes;
+        out[i].genes = nullptr;
+        if (out[i].n_genes > 0) {
+            out[i].genes = (phx_gene *)malloc(sizeof(phx_gene) * (size_t)out[i].n_genes);
+            if (!out[i].genes) return PHX_E_NOMEM;
+            for (int k = 0; k < out[i].n_genes; k++) {
+                const DGene &g = c->h_genes[(size_t)(m.gene_off + k)];
+                out[i].genes[k].left = g.left; out[i].genes[k].right = g.right;
+                out[i].genes[k].strand = g.strand; out[i].genes[k].frame = g.frame;
+                out[i].genes[k].score = g.score;
+            }
+        }
+    }
+    return PHX_OK;
+}
+
+int phx_annotate(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len, phx_result *out) {
+    int rc = phx_upload(c, n, seq, len);
+    if (rc) return rc;
+    if ((rc = phx_run(c))) return rc;
+    return phx_download(c, out);
+}
+
+void phx_free_results(phx_result *res, int32_t n) {
+    if (!res) return;
+    for (int i = 0; i < n; i++) { free(res[i].genes); res[i].genes = nullptr; res[i].n_genes = 0; }
+}
+
+// ---- taps ----
+#define TAP_PRE(c, contig)                                            \
+    if (!(c)) return PHX_E_ARG;                                       \
+    if (!(c)->ran) return PHX_E_STATE;                                \
+    if ((contig) < 0 || (contig) >= (c)->n) return PHX_E_ARG;         \
+    HIPCHK(c, hipSetDevice((c)->device));                             \
+    const DMeta &m = (c)->meta[(size_t)(contig)];
+
+static double host_contig_pstop(uint32_t gc, int L) {
+    double fa = (double)((uint32_t)L - gc), fg = (double)gc, d = (double)((int64_t)L * 2);
+    double Pa = fa / d, Pt = fa / d, Pg = fg / d;
+    return Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
+}
+
+int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
+    TAP_PRE(c, contig);
+    if (!out) return PHX_E_ARG;
+    memset(out, 0, sizeof(*out));
+    out->L = m.L;
+    out->status = m.status;
+    out->n_limbs = c->n_limbs;
+    if (m.status < 0) return PHX_OK;
+    out->pstop = host_contig_pstop(m.gc, m.L);
+    double bgs = 0, trs = 0;
+    for (int i = 0; i < 28; i++) { bgs += 1.0 + (double)m.bg[i]; trs += 1.0 + (double)m.tr[i]; }
+    for (int i = 0; i < 28; i++) { out->background_rbs[i] = (1.0 + (double)m.bg[i]) / bgs; out->training_rbs[i] = (1.0 + (double)m.tr[i]) / trs; }
+    double ymx = 1, ymn = 1;
+    for (int i = 0; i < 4; i++) {
+        out->pos_max[i] = 1.0 + (double)(i ? m.pmax[i] : 0u); out->pos_min[i] = 1.0 + (double)(i ? m.pmin[i] : 0u);
+        ymx = std::max(ymx, out->pos_max[i]); ymn = std::max(ymn, out->pos_min[i]);
+    }
+    for (int i = 0; i < 4; i++) { out->pos_max[i] /= ymx; out->pos_min[i] /= ymn; }
+    out->n_orf = m.n_orf; out->n_group = m.n_grp; out->n_node = m.n_node; out->n_edge = m.n_edge; out->n_bridge = m.n_bridge;
+    out->sssp_sweeps = m.sweeps;
+    return PHX_OK;
+}
+
+int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, uint8_t *binF, uint8_t *binR) {
+    TAP_PRE(c, contig);
+    const size_t L = (size_t)m.L;
+    if (cls) HIPCHK(c, hipMemcpy(cls, (uint8_t *)c->b_cls.p + m.off, L, hipMemcpyDeviceToHost));
+    if (gcc) HIPCHK(c, hipMemcpy(gcc, (uint8_t *)c->b_gcc.p + m.off, L, hipMemcpyDeviceToHost));
+    if (binF || binR) {
+        std::vector<uint16_t> r(L);
+        HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < L; i++) { if (binF) binF[i] = (uint8_t)(r[i] & 31u); if (binR) binR[i] = (uint8_t)((r[i] >> 5) & 31u); }
+    }
+    return PHX_OK;
+}
+
+int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
+    TAP_PRE(c, contig);
+    if (m.status < 0 || m.n_orf == 0) return PHX_OK;
+    if (!out) return PHX_E_ARG;
+    std::vector<DOrf> d((size_t)m.n_orf);
+    HIPCHK(c, hipMemcpy(d.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * d.size(), hipMemcpyDeviceToHost));
+    phx_globals gl;
+    phx_tap_globals(c, contig, &gl);
+    for (size_t k = 0; k < d.size(); k++) {
+        const DOrf &r = d[k];
+        phx_orf &o = out[k];
+        o.start = r.start; o.stop = r.stop; o.frame = r.frame;
+        o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
+        o.rbs = r.rbs; o.startidx = r.startidx; o.group = r.grp;
+        double S = 0;
+        for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = r.hist[a * 3 + cc]; S += (double)r.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
+        o.S = S;
+        o.pstop = r.pstop;
+        o.weight_rbs = gl.training_rbs[r.rbs] / gl.background_rbs[r.rbs];
+        o.weight = r.weight;
+    }
+    return PHX_OK;
+}
+
+int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
+    TAP_PRE(c, contig);
+    if (m.status < 0 || m.n_node == 0) return PHX_OK;
+    if (!out) return PHX_E_ARG;
+    const size_t V = (size_t)m.n_node;
+    std::vector<int32_t> npos(V), ninfo(V), nother(V);
+    std::vector<uint32_t> nlink(V);
+    std::vector<double> no(V);
+    std::vector<DGrp> grp((size_t)m.n_grp);
+    std::vector<DOrf> orf((size_t)m.n_orf);
+    HIPCHK(c, hipMemcpy(npos.data(), (int32_t *)c->b_npos.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ninfo.data(), (int32_t *)c->b_ninfo.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nother.data(), (int32_t *)c->b_nother.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nlink.data(), (uint32_t *)c->b_nlink.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(no.data(), (double *)c->b_no.p + m.node_off, V * 8, hipMemcpyDeviceToHost));
+    if (m.n_grp) HIPCHK(c, hipMemcpy(grp.data(), (DGrp *)c->b_grp.p + m.grp_off, sizeof(DGrp) * grp.size(), hipMemcpyDeviceToHost));
+    if (m.n_orf) HIPCHK(c, hipMemcpy(orf.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * orf.size(), hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < V; v++) {
+        out[v].pos = npos[v]; out[v].type = (int8_t)NTYPE(ninfo[v]); out[v].frame = (int8_t)NFRAME(ninfo[v]); out[v].pad = 0;
+        out[v].other = nother[v]; out[v].o = no[v];
+        // reference insertion rank (functions.py:311-318): per ORF (source, target) in iter_orfs order
+        int ref = -1;
+        if (v + 2 == V) ref = m.n_orf + m.n_grp;
+        else if (v + 1 == V) ref = m.n_orf + m.n_grp + 1;
+        else if (LINK_KIND(nlink[v]) == LINK_STOP) {
+            const int g = (int)LINK_IDX(nlink[v]);
+            ref = grp[(size_t)g].orf_begin + g + (grp[(size_t)g].frame > 0 ? 1 : 0);
+        } else {
+            const int k = (int)LINK_IDX(nlink[v]);
+            const int g = orf[(size_t)k].grp;
+            const int mth = k - grp[(size_t)g].orf_begin;
+            const int base = grp[(size_t)g].orf_begin + g;
+            ref = grp[(size_t)g].frame > 0 ? (mth == 0 ? base : base + 1 + mth) : base + 1 + mth;
+        }
+        out[v].refidx = ref;
+    }
+    return PHX_OK;
+}
+
+int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
+    TAP_PRE(c, contig);
+    if (m.status < 0 || m.n_edge == 0) return PHX_OK;
+    if (!out) return PHX_E_ARG;
+    const size_t V = (size_t)m.n_node, E = (size_t)m.n_edge;
+    std::vector<uint32_t> in_off(V + 1), esrc(E);
+    std::vector<double> ew(E);
+    HIPCHK(c, hipMemcpy(in_off.data(), (uint32_t *)c->b_inoff.p + m.node_off + contig, (V + 1) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(esrc.data(), (uint32_t *)c->b_esrc.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ew.data(), (double *)c->b_ew.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
+    for (size_t v = 0; v < V; v++)
+        for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) { out[e].src = (int32_t)esrc[e]; out[e].dst = (int32_t)v; out[e].w = ew[e]; }
+    return PHX_OK;
+}
+
+int phx_tap_path(phx_ctx *c, int32_t contig, int32_t *path, int32_t cap, int32_t *n_path, uint64_t *dist_limbs, int32_t cap_limbs) {
+    TAP_PRE(c, contig);
+    if (n_path) *n_path = 0;
+    if (m.status < 0 || m.n_path == 0) return PHX_OK;
+    if (n_path) *n_path = m.n_path;
+    if (path) {
+        if (cap < m.n_path) return PHX_E_ARG;
+        HIPCHK(c, hipMemcpy(path, (int32_t *)c->b_path.p + m.node_off, (size_t)m.n_path * 4, hipMemcpyDeviceToHost));
+    }
+    if (dist_limbs) {
+        if (cap_limbs < c->n_limbs) return PHX_E_ARG;
+        const size_t tgt = (size_t)m.node_off + (size_t)m.n_node - 1;
+        HIPCHK(c, hipMemcpy(dist_limbs, (uint64_t *)c->b_dist.p + tgt * (size_t)c->n_limbs, (size_t)c->n_limbs * 8, hipMemcpyDeviceToHost));
+    }
+    return PHX_OK;
+}
+
+// ---- the solver alone ----
+int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs, int32_t n_limbs,
+              int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path, uint64_t *dist_limbs) {
+    if (!c || V < 2 || E < 0 || (E > 0 && (!src || !dst || !w_limbs)) || !n_path) return PHX_E_ARG;
+    if (!(n_limbs == 2 || n_limbs == 4 || n_limbs == 8 || n_limbs == 17)) return PHX_E_ARG;
+    if (source < 0 || source >= V || target < 0 || target >= V || source == target) return PHX_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_path = 0;
+    // device node order: everything else in given order, then source (V-2), then target (V-1)
+    std::vector<int32_t> to_dev((size_t)V), to_user((size_t)V);
+    {
+        int k = 0;
+        for (int v = 0; v < V; v++) if (v != source && v != target) { to_dev[(size_t)v] = k; to_user[(size_t)k] = v; k++; }
+        to_dev[(size_t)source] = V - 2; to_user[(size_t)V - 2] = source;
+        to_dev[(size_t)target] = V - 1; to_user[(size_t)V - 1] = target;
+    }
+    std::vector<uint32_t> in_off((size_t)V + 1, 0), esrc((size_t)E);
+    std::vector<uint64_t> ewl((size_t)E * (size_t)n_limbs);
+    for (int e = 0; e < E; e++) {
+        if (src[e] < 0 || src[e] >= V || dst[e] < 0 || dst[e] >= V) return PHX_E_ARG;
+        in_off[(size_t)to_dev[(size_t)dst[e]] + 1]++;
+    }
+    for (int v = 0; v < V; v++) in_off[(size_t)v + 1] += in_off[(size_t)v];
+    {
+        std::vector<uint32_t> fill(in_off.begin(), in_off.end() - 1);
+        for (int e = 0; e < E; e++) { // stable: in-edge order of a node = order of the caller's edge list
+            uint32_t k = fill[(size_t)to_dev[(size_t)dst[e]]]++;
+            esrc[k] = (uint32_t)to_dev[(size_t)src[e]];
+            memcpy(&ewl[(size_t)k * (size_t)n_limbs], &w_limbs[(size_t)e * (size_t)n_limbs], (size_t)n_limbs * 8);
+        }
+    }
+    DMeta m;
+    memset(&m, 0, sizeof(m));
+    m.n_node = V; m.n_edge = E; m.L = 1;
+    int rc;
+    DevBuf &b_meta = c->b_meta;
+    if ((rc = ensure(c, b_meta, sizeof(DMeta) * 2))) return rc;
+    if ((rc = ensure(c, c->b_inoff, ((size_t)V + 2) * 4))) return rc;
+    if ((rc = ensure(c, c->b_esrc, ((size_t)E + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_ew, ((size_t)E + 1) * 8))) return rc;
+    if ((rc = ensure(c, c->b_ewl, ((size_t)E + 1) * 8 * (size_t)n_limbs))) return rc;
+    if ((rc = ensure(c, c->b_dist, ((size_t)V + 1) * 8 * (size_t)n_limbs))) return rc;
+    if ((rc = ensure(c, c->b_parent, ((size_t)V + 1) * 4))) return rc;
+    c->uploaded = false; c->ran = false; // the batch buffers are being reused
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(b_meta.p, &m, sizeof(m), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->b_inoff.p, in_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, s));
+    if (E) {
+        HIPCHK(c, hipMemcpyAsync(c->b_esrc.p, esrc.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_ewl.p, ewl.data(), (size_t)E * 8 * (size_t)n_limbs, hipMemcpyHostToDevice, s));
+    }
+    DBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n_contig = 1;
+    b.meta = (DMeta *)b_meta.p;
+    b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (double *)c->b_ew.p;
+    b.ewl = (const uint64_t *)c->b_ewl.p;
+    b.dist = (uint64_t *)c->b_dist.p; b.parent = (int32_t *)c->b_parent.p;
+    phxk_sssp(&b, n_limbs, s);
+    HIPCHK(c, hipGetLastError());
+    std::vector<int32_t> parent((size_t)V);
+    std::vector<uint64_t> dist((size_t)V * (size_t)n_limbs);
+    HIPCHK(c, hipMemcpyAsync(parent.data(), c->b_parent.p, (size_t)V * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(dist.data(), c->b_dist.p, (size_t)V * 8 * (size_t)n_limbs, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&m, b_meta.p, sizeof(m), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (m.status < 0) return m.status;
+    const uint64_t *dt = &dist[(size_t)(V - 1) * (size_t)n_limbs];
+    if (dt[n_limbs - 1] == 0x7fffffffffffffffull) return PHX_OK; // unreachable: *n_path = 0
+    std::vector<int32_t> rev;
+    for (int v = V - 1; v != V - 2 && (int)rev.size() <= V; v = parent[(size_t)v]) rev.push_back(v);
+    rev.push_back(V - 2);
+    if ((int)rev.size() > cap && path_out) return PHX_E_ARG;
+    *n_path = (int32_t)rev.size();
+    if (path_out) for (size_t k = 0; k < rev.size(); k++) path_out[k] = to_user[(size_t)rev[rev.size() - 1 - k]];
+    if (dist_limbs) memcpy(dist_limbs, dt, (size_t)n_limbs * 8);
+    return PHX_OK;
+}
+
+// ---- measurement ----
+int phx_set_profiling(phx_ctx *c, int on) {
+    if (!c) return PHX_E_ARG;
+    c->prof = on != 0;
+    return PHX_OK;
+}
+int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
+    if (!c) return PHX_E_ARG;
+    for (int i = 0; i < PHX_N_STAGES; i++) { if (ms) ms[i] = c->stage_ms[i]; if (launches) launches[i] = c->stage_n[i]; }
+    if (reset) for (int i = 0; i < PHX_N_STAGES; i++) { c->stage_ms[i] = 0; c->stage_n[i] = 0; }
+    return PHX_OK;
+}
+const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
+int phx_batch_sizes(phx_ctx *c, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge) {
+    if (!c) return PHX_E_ARG;
+    if (L) *L = c->totalL;
+    if (n_orf) *n_orf = c->tot_orf;
+    if (n_node) *n_node = c->tot_node;
+    if (n_edge) *n_edge = c->tot_edge;
+    return PHX_OK;
+}
+
+} // extern "C"

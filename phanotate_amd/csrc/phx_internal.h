@@ -1,0 +1,157 @@
+// phx_internal.h — device/host shared layouts of libphx (not part of the public ABI).
+//
+// Data layout in HBM (one batch = n contigs, concatenated):
+//   per position (index = meta.off + p, p 0-based):  ascii u8, cls u8, gcc u8, cnt u8, rbs u16,
+//       linkF u32, linkR u32, cov u8          (linkF/linkR/cov are indexed by 1-based position - 1)
+//   per ORF   (index = meta.orf_off + k, k in reference iter_orfs order):  DOrf (56 B)
+//   per group (index = meta.grp_off + g, g in reference insertion order):  DGrp (24 B)
+//   per node  (index = meta.node_off + v, v sorted by position; source = V-2, target = V-1):
+//       npos i32, ninfo i32, nlink u32, nother i32, no f64, in_off u32 (+1), dist NL x u64, parent i32
+//   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32, ew f64
+#pragma once
+#include <stdint.h>
+
+#include "../../include/phx.h"
+
+#define PHX_TILE 2048       // positions per feature-kernel workgroup
+#define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
+#define PHX_FEAT_THREADS 256
+#define PHX_CTG_THREADS 256 // per-contig workgroup kernels
+#define PHX_MAX_BRIDGE 64
+
+// codon classes, in the elif order of functions.py:198-215
+#define CLS_NONE 0
+#define CLS_FS 1 // codon in start_codons
+#define CLS_RS 2 // rev_comp(codon) in start_codons
+#define CLS_FT 3 // codon in stop_codons
+#define CLS_RT 4 // rev_comp(codon) in stop_codons
+// cls byte: bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
+
+// node link word: bits 30-31 kind, bits 0-29 index
+#define LINK_NONE 0u
+#define LINK_START (1u << 30) // payload = ORF index (contig-relative)
+#define LINK_STOP (2u << 30)  // payload = group index (contig-relative)
+#define LINK_IDX(x) ((x)&0x3fffffffu)
+#define LINK_KIND(x) ((x)&0xc0000000u)
+
+// ninfo: bits0-1 type (0 start,1 stop,2 source,3 target), bits 8-15 frame as int8
+#define NINFO(type, frame) ((int32_t)(((uint32_t)(type)&3u) | (((uint32_t)(uint8_t)(int8_t)(frame)) << 8)))
+#define NTYPE(i) ((i)&3)
+#define NFRAME(i) ((int)(int8_t)(((uint32_t)(i) >> 8) & 0xff))
+
+struct DParams { // device copy of phx_params + derived tables
+    int32_t minlen;
+    int32_t n_start;
+    double start_w[PHX_MAX_CODONS];
+    uint8_t cls_tab[64];  // codon code (c0 | c1<<2 | c2<<4) -> cls byte
+    uint8_t atg_tab[64];  // bit0: codon == 'atg', bit1: codon == 'cat'
+};
+
+struct DOrf {
+    int32_t start, stop; // reference Orf.start / Orf.stop (1-based)
+    int8_t frame;        // +-1..3
+    uint8_t rbs;         // score_rbs bin
+    int8_t startidx;     // index into params.start or -1
+    uint8_t flags;       // bit0: Orf.start_codon() == 'atg'
+    int32_t grp;         // contig-relative group index
+    int32_t node;        // device node id of the start node
+    uint16_t hist[9];    // GC frame class histogram over the sense codons
+    uint16_t pad;
+    double pstop;
+    double weight;
+};
+
+struct DGrp {
+    int32_t stop;      // dict key
+    int32_t orf_begin; // contig-relative index of the first ORF; ORFs are contiguous, nearest start first
+    int32_t n;
+    int32_t node; // device node id of the stop node
+    int32_t frame;
+    int32_t pad;
+};
+
+struct DBridge {
+    int32_t last, base;
+};
+
+struct DMeta { // one per contig
+    int64_t off; // position offset into per-position arrays
+    int32_t L;
+    int32_t status;
+    uint32_t gc;       // g+c after the counting remap of functions.py:159-163
+    uint32_t bg[28];   // background RBS bin counts (no pseudo-count)
+    uint32_t tr[28];   // training RBS bin counts
+    uint32_t pmax[4];  // GC-frame training counts, index 1..3
+    uint32_t pmin[4];
+    int32_t n_orf, n_grp;
+    int64_t orf_off, grp_off;
+    int32_t n_node; // including source and target
+    int32_t n_edge;
+    int64_t node_off, edge_off;
+    int32_t n_bridge;
+    int32_t maxexp; // max binary exponent of |trunc(w*1000)| over the ORF edges
+    DBridge bridge[PHX_MAX_BRIDGE];
+    int32_t n_genes;
+    int32_t n_path;
+    int64_t gene_off;
+    int32_t sweeps;
+    int32_t pad;
+};
+
+struct DTile {
+    int32_t contig;
+    int32_t p0;
+};
+
+struct DGene {
+    int32_t left, right, strand, frame;
+    double score;
+};
+
+// Everything the kernels need, passed by value.
+struct DBatch {
+    int32_t n_contig;
+    DMeta *meta;
+    const DParams *params;
+    const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;
+    // per position
+    const uint8_t *ascii;
+    uint8_t *cls, *gcc, *cnt, *cov;
+    uint16_t *rbs;
+    uint32_t *linkF, *linkR;
+    // per ORF / group
+    DOrf *orf;
+    DGrp *grp;
+    // per node
+    int32_t *npos, *ninfo, *nother, *parent;
+    uint32_t *nlink, *in_off;
+    double *no;
+    uint64_t *dist;
+    // per edge
+    uint32_t *esrc;
+    double *ew;
+    const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge
+    // output
+    int32_t *path;
+    DGene *genes;
+    uint32_t *gene_total;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// kernel launchers (phx_kernels.hip); all asynchronous on `stream`
+void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream);
+void phxk_orf_count(const DBatch *b, void *stream);
+void phxk_orf_emit(const DBatch *b, void *stream);
+void phxk_orf_stats(const DBatch *b, void *stream);
+void phxk_train(const DBatch *b, void *stream);
+void phxk_score(const DBatch *b, void *stream);
+void phxk_nodes(const DBatch *b, void *stream);
+void phxk_edges_count(const DBatch *b, void *stream);
+void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_sssp(const DBatch *b, int n_limbs, void *stream);
+void phxk_path(const DBatch *b, int n_limbs, void *stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,1089 @@
+// phx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels for PHANOTATE's per-contig hot path.
+//
+// Stage           kernel            granularity                       reference code restated
+// -------------   ---------------   -------------------------------   ---------------------------------------
+// features        k_features        1 workgroup / 2048-position tile   functions.py:158-171 (per-base loop),
+//                                                                      score_rbs 48-138, gc_frame_plot.py:29-74
+// ORF scan        k_orf<EMIT>       1 workgroup / contig               functions.py:184-251, orfs.py:17-32
+// ORF stats       k_orf_stats       thread / ORF, thread / group       orfs.py:162-173, functions.py:261-279,286-298
+// ORF score       k_score           thread / ORF                       functions.py:254-257,281-284,300-301, orfs.py:122-127
+// nodes           k_nodes           1 workgroup / contig               functions.py:311-318 (nodes), 320-333 (coverage),
+//                                                                      363-384 (other_end / o1,o2)
+// edges           k_edges<FILL>     thread / destination node          functions.py:334-354, 360-452
+// shortest path   k_sssp<NL>        1 workgroup / contig               fastpathz (phanotate.py:56-64), exact NL x 64-bit ints
+// genes           k_path<NL>        thread / contig                    phanotate.py:65-76, locus.py:29-37
+//
+// No MFMA anywhere: the path has no dense contraction.  All integer outputs are
+// bit-exact with the reference; fp64 is used where the reference uses Decimal (edge weights only).
+#include <hip/hip_runtime.h>
+
+#include "phx_internal.h"
+
+#define NT PHX_CTG_THREADS
+
+// ------------------------------------------------------------------------------------------------
+// wave / block primitives (wave64)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= d) v = v > t ? v : t;
+    }
+    return v;
+}
+// Exclusive block sum-scan over N threads (N multiple of 64, <= 1024). lds: N/64+1 words.
+template <int N>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *lds, uint32_t *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < N / 64; i++) { uint32_t t = lds[i]; lds[i] = s; s += t; }
+        lds[N / 64] = s;
+    }
+    __syncthreads();
+    uint32_t r = inc - v + lds[w];
+    *total = lds[N / 64];
+    __syncthreads();
+    return r;
+}
+// Exclusive block max-scan (identity 0).
+template <int N>
+__device__ __forceinline__ uint32_t block_excl_max(uint32_t v, uint32_t *lds, uint32_t *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_max(v);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < N / 64; i++) { uint32_t t = lds[i]; lds[i] = s; s = s > t ? s : t; }
+        lds[N / 64] = s;
+    }
+    __syncthreads();
+    uint32_t prev = __shfl_up(inc, 1);
+    if (lane == 0) prev = 0;
+    uint32_t r = prev > lds[w] ? prev : lds[w];
+    *total = lds[N / 64];
+    __syncthreads();
+    return r;
+}
+
+// functions.py:174-178: both strands are counted, so Pa == Pt and Pg == Pc.
+__device__ __forceinline__ double contig_pstop(uint32_t gc, int L) {
+    double fa = (double)((uint32_t)L - gc), fg = (double)gc;
+    double d = (double)((int64_t)L * 2);
+    double Pa = fa / d, Pt = fa / d, Pg = fg / d;
+    return Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
+}
+// gc_frame_plot.py:7-28
+__device__ __forceinline__ int max_idx(int a, int b, int c) { return a > b ? (a > c ? 1 : 3) : (b > c ? 2 : 3); }
+__device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b > c ? 3 : 2) : (a > c ? 3 : 1); }
+
+// ------------------------------------------------------------------------------------------------
+// k_features: ASCII -> per-position feature bytes.  Base code: a=0 c=1 t=2 g=3 (complement = x^2,
+// GC = x&1); bit2 = "cannot match a motif/codon" (ambiguity code or outside the contig), bit3 = outside.
+#define FW (PHX_TILE + 2 * PHX_HALO)
+
+__device__ __forceinline__ uint32_t base_code(uint32_t ch, bool &bad) {
+    if (ch >= 'A' && ch <= 'Z') ch |= 0x20u; // .lower(), functions.py:144
+    switch (ch) {
+    case 'a': return 0; case 'c': return 1; case 't': return 2; case 'g': return 3;
+    case 's': case 'b': case 'v': return 3u | 4u; // counted as g, functions.py:160-161
+    case 'n': case 'r': case 'y': case 'w': case 'k': case 'm': case 'd': case 'h': return 0u | 4u; // counted as a
+    default: bad = true; return 0u | 4u; // KeyError in rev_comp, functions.py:20-24
+    }
+}
+__device__ __forceinline__ int off_class(int o) { return o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)); }
+
+// packed per-class scores of the k-mers that start at s[0] (k = 3..min(6,vmax)), given the 6 symbols
+__device__ __forceinline__ uint32_t kmer_lookup(const uint32_t *t6, const uint32_t *t5, const uint32_t *t4, const uint32_t *t3,
+                                                uint32_t code, int v) {
+    if (v >= 6) return t6[code & 4095u];
+    if (v == 5) return t5[code & 1023u];
+    if (v == 4) return t4[code & 255u];
+    if (v == 3) return t3[code & 63u];
+    return 0u;
+}
+
+__global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const DTile *__restrict__ tiles) {
+    __shared__ uint8_t s_code[FW];
+    __shared__ uint16_t s_pref[FW];
+    __shared__ uint8_t s_W[FW];
+    __shared__ uint32_t s_AF[FW], s_AR[FW];
+    __shared__ uint32_t s_t6[4096], s_t5[1024], s_t4[256], s_t3[64];
+    __shared__ uint32_t s_hist[28];
+    __shared__ uint32_t s_scan[PHX_FEAT_THREADS / 64 + 1];
+    __shared__ uint32_t s_gc, s_bad;
+
+    const int tid = threadIdx.x;
+    const DTile tile = tiles[blockIdx.x];
+    DMeta *meta = &b.meta[tile.contig];
+    const int L = meta->L;
+    const int64_t off = meta->off;
+    const int p0 = tile.p0;
+    const uint8_t *__restrict__ ascii = b.ascii + off;
+
+    for (int i = tid; i < 4096; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
+    for (int i = tid; i < 1024; i += PHX_FEAT_THREADS) s_t5[i] = b.rbs_t5[i];
+    if (tid < 256) s_t4[tid] = b.rbs_t4[tid];
+    if (tid < 64) s_t3[tid] = b.rbs_t3[tid];
+    if (tid < 28) s_hist[tid] = 0;
+    if (tid == 0) { s_gc = 0; s_bad = 0; }
+
+    // 1. stage the tile (+halo) as base codes
+    bool bad = false;
+    uint32_t mygc = 0;
+    for (int idx = tid; idx < FW; idx += PHX_FEAT_THREADS) {
+        int p = p0 - PHX_HALO + idx;
+        uint32_t c;
+        if (p < 0 || p >= L) c = 8u | 4u;
+        else {
+            c = base_code(ascii[p], bad);
+            if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE) mygc += c & 1u;
+        }
+        s_code[idx] = (uint8_t)c;
+    }
+    __syncthreads();
+
+    // 2. per-residue exclusive GC prefix over the window (three interleaved sums, packed 3 x 10 bit)
+    {
+        const int i0 = tid * 9;
+        uint32_t loc = 0;
+        for (int k = 0; k < 9; k++) {
+            int idx = i0 + k;
+            if (idx < FW) loc += (uint32_t)(s_code[idx] & 1u) << (10 * (k % 3));
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan<PHX_FEAT_THREADS>(loc, s_scan, &tot);
+        uint32_t run[3] = {ex & 1023u, (ex >> 10) & 1023u, (ex >> 20) & 1023u};
+        for (int k = 0; k < 9; k++) {
+            int idx = i0 + k;
+            if (idx < FW) {
+                s_pref[idx] = (uint16_t)run[k % 3];
+                run[k % 3] += s_code[idx] & 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. W(q) = GC count over q+3m, m in [-19,20] (gc_frame_plot.py:44-59); k-mer class scores
+    for (int idx = tid; idx < FW; idx += PHX_FEAT_THREADS) {
+        if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE + 2)
+            s_W[idx] = (uint8_t)(s_pref[idx + 60] + (s_code[idx + 60] & 1u) - s_pref[idx - 57]);
+        uint32_t af = 0, ar = 0;
+        if (idx >= 5) { // leftward 6-mer: s[k] = dna[y-k]
+            uint32_t code = 0; int v = 0; bool ok = true;
+            for (int k = 0; k < 6; k++) {
+                uint32_t c = s_code[idx - k];
+                ok = ok && !(c & 4u);
+                if (ok) v++;
+                code |= (c & 3u) << (2 * k);
+            }
+            af = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
+        }
+        if (idx + 5 < FW) { // rightward complemented 6-mer: s[k] = comp(dna[y+k])
+            uint32_t code = 0; int v = 0; bool ok = true;
+            for (int k = 0; k < 6; k++) {
+                uint32_t c = s_code[idx + k];
+                ok = ok && !(c & 4u);
+                if (ok) v++;
+                code |= ((c & 3u) ^ 2u) << (2 * k);
+            }
+            ar = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
+        }
+        s_AF[idx] = af;
+        s_AR[idx] = ar;
+    }
+    __syncthreads();
+
+    // 4. per-position outputs
+    const DParams *P = b.params;
+    for (int j = tid; j < PHX_TILE; j += PHX_FEAT_THREADS) {
+        const int p = p0 + j;
+        if (p >= L) break;
+        const int idx = PHX_HALO + j;
+        const uint32_t c0 = s_code[idx], c1 = s_code[idx + 1], c2 = s_code[idx + 2];
+        uint32_t cls = 0, atg = 0, gcc = 0, cnt = 0;
+        if (p <= L - 3) {
+            if (!((c0 | c1 | c2) & 4u)) {
+                uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
+                cls = P->cls_tab[ci];
+                atg = P->atg_tab[ci];
+            }
+            int w0 = s_W[idx], w1 = s_W[idx + 1], w2 = s_W[idx + 2];
+            uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
+            uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
+            gcc = f | (r << 4);
+        }
+        { // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7
+            const uint32_t cc[3] = {c0, c1, c2};
+            for (int k = 0; k < 3; k++)
+                if (!(cc[k] & 4u)) {
+                    uint32_t x = cc[k] & 3u; // a0 c1 t2 g3
+                    cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
+                }
+        }
+        // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21])
+        uint32_t bf = 0, br = 0;
+        if (p >= 20) {
+            for (int o = 3; o <= 15; o++) {
+                uint32_t s = (s_AF[idx - o] >> (8 * off_class(o))) & 0xffu;
+                bf = s > bf ? s : bf;
+            }
+            atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
+        }
+        for (int o = 3; o <= 15; o++) {
+            uint32_t s = (s_AR[idx + o] >> (8 * off_class(o))) & 0xffu;
+            br = s > br ? s : br;
+        }
+        atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
+        b.cls[off + p] = (uint8_t)cls;
+        b.gcc[off + p] = (uint8_t)gcc;
+        b.cnt[off + p] = (uint8_t)cnt;
+        b.rbs[off + p] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
+    }
+    // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
+    // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
+    if (L - 1 >= p0 && L - 1 < p0 + PHX_TILE) {
+        const int nt = L < 20 ? L : 20;
+        if (tid < nt) {
+            const int len = tid + 1;
+            const int ie = PHX_HALO + (L - 1 - p0);
+            uint32_t best = 0;
+            for (int o = 3; o <= 15; o++) {
+                int vmax = len - o;
+                if (vmax < 3) break;
+                if (vmax > 6) vmax = 6;
+                uint32_t code = 0; int v = 0; bool ok = true;
+                for (int k = 0; k < vmax; k++) {
+                    uint32_t c = s_code[ie - o - k];
+                    ok = ok && !(c & 4u);
+                    if (ok) v++;
+                    code |= (c & 3u) << (2 * k);
+                }
+                uint32_t s = (kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v) >> (8 * off_class(o))) & 0xffu;
+                best = s > best ? s : best;
+            }
+            atomicAdd(&s_hist[best], 1u);
+        }
+    }
+    if (mygc) atomicAdd(&s_gc, mygc);
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (tid < 28 && s_hist[tid]) atomicAdd(&meta->bg[tid], s_hist[tid]);
+    if (tid == 0) {
+        if (s_gc) atomicAdd(&meta->gc, s_gc);
+        if (s_bad) atomicMin(&meta->status, PHX_S_BADLETTER);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORF scan.  One workgroup per contig walks the positions in order; a thread that sits on a stop
+// event (forward stop codon, or the closing reverse-complement stop codon) owns that stop-group.
+struct OrfOut {
+    DOrf *orf;
+    DGrp *grp;
+    uint32_t *linkF, *linkR;
+};
+
+// Forward group closed by the stop codon (or, for the end fragment, the last codon of the frame) at 0-based p:
+// functions.py:202-214 / 229-239.  Starts are visited nearest first == reversed(starts[frame]).
+template <bool EMIT>
+__device__ int fwd_group(const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int p, int minlen, OrfOut o, int obase, int gidx) {
+    int n = 0;
+    int q;
+    for (q = p - 3; q >= 0; q -= 3) {
+        const uint32_t cb = cls[q];
+        const int c = cb & 7;
+        if (c == CLS_FT) break;
+        if (c == CLS_FS && p - q + 3 >= minlen) {
+            if (EMIT) {
+                DOrf *r = &o.orf[obase + n];
+                r->start = q + 1; r->stop = p + 1; r->frame = (int8_t)(p % 3 + 1);
+                r->rbs = (uint8_t)(q >= 20 ? (rbs[q] & 31u) : 0u); // dna[start-21:start] is empty for start < 21 (functions.py:208)
+                r->startidx = (int8_t)((cb >> 3) & 15);
+                r->flags = (uint8_t)((rbs[q] >> 10) & 1u);
+                r->grp = gidx; r->node = -1;
+                o.linkF[q] = LINK_START | (uint32_t)(obase + n);
+            }
+            n++;
+        }
+    }
+    if (q < 0) { // no stop to the left: the frame opens with a pseudo-start unless its first codon is a start (functions.py:186-191)
+        const int q0 = p % 3;
+        if ((cls[q0] & 7) != CLS_FS && q0 < p && p - q0 + 3 >= minlen) {
+            if (EMIT) {
+                DOrf *r = &o.orf[obase + n];
+                r->start = q0 + 1; r->stop = p + 1; r->frame = (int8_t)(p % 3 + 1);
+                r->rbs = 0; // start <= 3 < 21
+                r->startidx = -1;
+                r->flags = (uint8_t)((rbs[q0] >> 10) & 1u);
+                r->grp = gidx; r->node = -1;
+                o.linkF[q0] = LINK_START | (uint32_t)(obase + n);
+            }
+            n++;
+        }
+    }
+    if (EMIT && n) {
+        DGrp *g = &o.grp[gidx];
+        g->stop = p + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = p % 3 + 1; g->pad = 0;
+        o.linkF[p] = LINK_STOP | (uint32_t)gidx;
+    }
+    return n;
+}
+
+// Reverse group: ORFs between the previous rc-stop of the frame and the pending rc-starts, emitted when
+// the closing rc-stop at p is met (functions.py:215-227), or after the loop for the open group
+// (functions.py:240-251; then `virt` is set, qe = last complete codon of the frame, and a pseudo-start
+// sits on qe unless rev_comp(codon) is a start codon).  Starts ascend == order of starts[-frame].
+template <bool EMIT>
+__device__ int rev_group(const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int p, bool virt, int L, int minlen, OrfOut o, int obase, int gidx) {
+    // previous stop of this frame: a real RT codon, or the frame's first position (stops = {-1:1,-2:2,-3:3}, functions.py:184)
+    int q = virt ? p : p - 3;
+    for (; q >= 0; q -= 3)
+        if ((cls[q] & 7) == CLS_RT) break;
+    const int sk = q >= 0 ? q : p % 3; // 0-based stop key
+    const int shi = virt ? p : p - 3;
+    int n = 0;
+    for (int s = sk + 3; s <= shi; s += 3) {
+        const uint32_t cb = cls[s];
+        bool real = (cb & 7) == CLS_RS;
+        bool pseudo = virt && s == p && !(cb & 0x80u);
+        if ((real || pseudo) && s - sk + 3 >= minlen) {
+            if (EMIT) {
+                DOrf *r = &o.orf[obase + n];
+                r->start = s + 1; r->stop = sk + 1; r->frame = (int8_t)(-(p % 3 + 1));
+                const int j = s + 3; // dna[start:start+21] with start = i+2 (functions.py:221)
+                r->rbs = (uint8_t)(j < L ? ((rbs[j] >> 5) & 31u) : 0u);
+                r->startidx = (int8_t)(real ? ((cb >> 3) & 15) : -1);
+                r->flags = (uint8_t)((rbs[s] >> 11) & 1u);
+                r->grp = gidx; r->node = -1;
+                o.linkR[s] = LINK_START | (uint32_t)(obase + n);
+            }
+            n++;
+        }
+    }
+    if (EMIT && n) {
+        DGrp *g = &o.grp[gidx];
+        g->stop = sk + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = -(p % 3 + 1); g->pad = 0;
+        o.linkR[sk] = LINK_STOP | (uint32_t)gidx;
+    }
+    return n;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(NT) void k_orf(DBatch b) {
+    __shared__ uint32_t s_scan[NT / 64 + 1];
+    DMeta *meta = &b.meta[blockIdx.x];
+    const int L = meta->L;
+    if (meta->status < 0 || L < 6) {
+        if (threadIdx.x == 0) {
+            if (L < 6 && meta->status == 0) meta->status = PHX_S_TOOSHORT;
+            meta->n_orf = 0; meta->n_grp = 0;
+        }
+        return;
+    }
+    const int64_t off = meta->off;
+    const uint8_t *__restrict__ cls = b.cls + off;
+    const uint16_t *__restrict__ rbs = b.rbs + off;
+    const int minlen = b.params->minlen;
+    OrfOut o;
+    o.orf = EMIT ? b.orf + meta->orf_off : nullptr;
+    o.grp = EMIT ? b.grp + meta->grp_off : nullptr;
+    o.linkF = b.linkF + off;
+    o.linkR = b.linkR + off;
+    int run_orf = 0, run_grp = 0;
+    // main loop, functions.py:195: codon starts i = 1..L-2  <=>  p = 0..L-3
+    for (int base = 0; base < L - 2; base += NT) {
+        const int p = base + (int)threadIdx.x;
+        int n = 0, c = 0;
+        if (p <= L - 3) {
+            c = cls[p] & 7;
+            if (c == CLS_FT) n = fwd_group<false>(cls, rbs, p, minlen, o, 0, 0);
+            else if (c == CLS_RT) n = rev_group<false>(cls, rbs, p, false, L, minlen, o, 0, 0);
+        }
+        uint32_t tot, gtot;
+        uint32_t ex = block_excl_scan<NT>((uint32_t)n, s_scan, &tot);
+        uint32_t gex = block_excl_scan<NT>(n ? 1u : 0u, s_scan, &gtot);
+        if (EMIT && n) {
+            if (c == CLS_FT) fwd_group<true>(cls, rbs, p, minlen, o, run_orf + (int)ex, run_grp + (int)gex);
+            else rev_group<true>(cls, rbs, p, false, L, minlen, o, run_orf + (int)ex, run_grp + (int)gex);
+        }
+        run_orf += (int)tot;
+        run_grp += (int)gtot;
+    }
+    // fragments at the right end, functions.py:229-251: frame 1 fwd, frame 1 rev, frame 2 fwd, ...
+    if (threadIdx.x == 0) {
+        for (int f = 0; f < 3; f++) {
+            if (L - f < 3) continue;
+            const int qe = f + 3 * ((L - f) / 3 - 1); // last complete codon of the frame
+            if ((cls[qe] & 7) != CLS_FT) { // else the main loop closed the group and starts[frame] is empty
+                int n = EMIT ? fwd_group<true>(cls, rbs, qe, minlen, o, run_orf, run_grp) : fwd_group<false>(cls, rbs, qe, minlen, o, 0, 0);
+                run_orf += n; run_grp += n ? 1 : 0;
+            }
+            int n = EMIT ? rev_group<true>(cls, rbs, qe, true, L, minlen, o, run_orf, run_grp) : rev_group<false>(cls, rbs, qe, true, L, minlen, o, 0, 0);
+            run_orf += n; run_grp += n ? 1 : 0;
+        }
+        if (!EMIT) { meta->n_orf = run_orf; meta->n_grp = run_grp; }
+        else if (run_orf != meta->n_orf || run_grp != meta->n_grp) meta->status = PHX_E_STATE; // cannot happen
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ORF statistics: GC-frame class histogram and p_stop of every ORF (thread per ORF), then the GC frame
+// plot training of functions.py:261-279 (thread per stop-group).
+__global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0) return;
+    const int64_t off = meta->off;
+    const uint8_t *__restrict__ gcc = b.gcc + off;
+    const uint8_t *__restrict__ cnt = b.cnt + off;
+    DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    for (int k = threadIdx.x; k < meta->n_orf; k += NT) {
+        DOrf *r = &orf[k];
+        const int start = r->start, stop = r->stop;
+        uint64_t h0 = 0, h1 = 0, h2 = 0; // classes 0-2, 3-5, 6-8 in 21-bit fields
+        uint32_t na = 0, nt = 0, ng = 0, nc = 0;
+        if (r->frame > 0) {
+            // sense codons start..stop-3 (functions.py:290); seq also holds the stop / last codon (functions.py:207)
+            for (int base = start; base <= stop; base += 3) {
+                const uint32_t cb = cnt[base - 1];
+                na += cb & 3u; nt += (cb >> 2) & 3u; ng += (cb >> 4) & 3u; nc += (cb >> 6) & 3u;
+                if (base < stop) {
+                    const uint32_t c = gcc[base - 1] & 15u;
+                    const uint64_t inc = 1ull << (21 * (c % 3));
+                    h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
+                }
+            }
+        } else {
+            // reverse: codons start, start-3, .., stop+3 (functions.py:295); seq = rev_comp(dna[stop-1:start+2])
+            for (int base = start; base >= stop; base -= 3) {
+                const uint32_t cb = cnt[base - 1];
+                na += cb & 3u; nt += (cb >> 2) & 3u; ng += (cb >> 4) & 3u; nc += (cb >> 6) & 3u;
+                if (base > stop) {
+                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
+                    const uint64_t inc = 1ull << (21 * (c % 3));
+                    h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
+                }
+            }
+            uint32_t t = na; na = nt; nt = t; // coding strand: a<->t, g<->c
+            ng = nc;
+        }
+        for (int i = 0; i < 3; i++) {
+            r->hist[i] = (uint16_t)((h0 >> (21 * i)) & 0x1fffff);
+            r->hist[3 + i] = (uint16_t)((h1 >> (21 * i)) & 0x1fffff);
+            r->hist[6 + i] = (uint16_t)((h2 >> (21 * i)) & 0x1fffff);
+        }
+        // Orf.p_stop, orfs.py:162-173
+        const int len = r->frame > 0 ? stop + 2 - start + 1 : start + 2 - stop + 1;
+        const double n = (double)len;
+        const double Pa = (double)na / n, Pt = (double)nt / n, Pg = (double)ng / n;
+        r->pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
+        atomicAdd(&meta->tr[r->rbs], 1u); // training_rbs, functions.py:211,224,239,251
+    }
+    // GC frame plot training: per group, the first ORF longest->shortest whose start codon is 'atg'
+    for (int g = threadIdx.x; g < meta->n_grp; g += NT) {
+        const DGrp G = grp[g];
+        for (int k = G.n - 1; k >= 0; k--) { // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46)
+            const DOrf *r = &orf[G.orf_begin + k];
+            if (!(r->flags & 1)) continue;
+            const int start = r->start, stop = r->stop;
+            uint32_t mx[4] = {0, 0, 0, 0}, mn[4] = {0, 0, 0, 0};
+            if (start < stop) {
+                const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
+                for (int base = start + nn; base < stop - 36; base += 3) {
+                    const uint32_t c = gcc[base - 1] & 15u;
+                    mx[c / 3 + 1]++; mn[c % 3 + 1]++;
+                }
+            } else if (stop < start) {
+                const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
+                for (int base = start - nn; base > stop + 36; base -= 3) {
+                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
+                    mx[c / 3 + 1]++; mn[c % 3 + 1]++;
+                }
+            }
+            for (int i = 1; i < 4; i++) {
+                if (mx[i]) atomicAdd(&meta->pmax[i], mx[i]);
+                if (mn[i]) atomicAdd(&meta->pmin[i], mn[i]);
+            }
+            break; // functions.py:279
+        }
+    }
+}
+
+// ORF weight: functions.py:254-257 (RBS), 281-284 (normalise), 286-301 + orfs.py:122-127.
+// hold = prod ((1-pstop)^pos_max[imax])^pos_min[imin] = (1-pstop)^S ; weight = -(1/hold)*w_start*w_rbs
+__global__ __launch_bounds__(NT) void k_score(DBatch b) {
+    __shared__ int s_maxexp;
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0) return;
+    if (threadIdx.x == 0) s_maxexp = 0;
+    __syncthreads();
+    DOrf *orf = b.orf + meta->orf_off;
+    const DParams *P = b.params;
+    double bgs = 0, trs = 0;
+    for (int i = 0; i < 28; i++) { bgs += 1.0 + (double)meta->bg[i]; trs += 1.0 + (double)meta->tr[i]; }
+    double pmax[4], pmin[4];
+    {
+        double ymx = 1.0, ymn = 1.0;
+        for (int i = 0; i < 4; i++) {
+            pmax[i] = 1.0 + (double)(i ? meta->pmax[i] : 0u);
+            pmin[i] = 1.0 + (double)(i ? meta->pmin[i] : 0u);
+            ymx = pmax[i] > ymx ? pmax[i] : ymx;
+            ymn = pmin[i] > ymn ? pmin[i] : ymn;
+        }
+        for (int i = 0; i < 4; i++) { pmax[i] /= ymx; pmin[i] /= ymn; }
+    }
+    int mymax = 0;
+    for (int k = threadIdx.x; k < meta->n_orf; k += NT) {
+        DOrf *r = &orf[k];
+        double S = 0;
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) S += (double)r->hist[a * 3 + c] * (pmax[a + 1] * pmin[c + 1]);
+        const double tr = (1.0 + (double)meta->tr[r->rbs]) / trs;
+        const double bg = (1.0 + (double)meta->bg[r->rbs]) / bgs;
+        const double w_rbs = tr / bg;
+        double s = exp(-S * log1p(-r->pstop));
+        if (r->startidx >= 0) s = s * P->start_w[r->startidx];
+        s = s * w_rbs;
+        r->weight = -s;
+        int e;
+        frexp(s * 1000.0, &e);
+        if (!(s < 1.0e300)) e = 4096; // inf / nan: force the overflow status
+        mymax = e > mymax ? e : mymax;
+    }
+    if (mymax) atomicMax(&s_maxexp, mymax);
+    __syncthreads();
+    if (threadIdx.x == 0) meta->maxexp = s_maxexp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nodes: one per ORF start and one per stop-group, sorted by position (then forward before reverse).
+// Also the coverage scan that finds the >500 bp uncovered runs of functions.py:320-334.
+struct LinkInfo { int time; int val; bool stop; int idx; };
+__device__ __forceinline__ LinkInfo link_info(uint32_t link, const DOrf *orf, const DGrp *grp) {
+    LinkInfo r;
+    r.idx = (int)LINK_IDX(link);
+    if (LINK_KIND(link) == LINK_START) { r.stop = false; r.time = r.idx; r.val = orf[r.idx].stop; }
+    else { r.stop = true; const DGrp g = grp[r.idx]; r.time = g.orf_begin + g.n - 1; r.val = orf[r.time].start; }
+    return r;
+}
+
+__global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
+    __shared__ uint32_t s_scan[NT / 64 + 1];
+    DMeta *meta = &b.meta[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (meta->status < 0) {
+        if (tid == 0) { meta->n_node = 0; meta->n_edge = 0; }
+        return;
+    }
+    const int L = meta->L;
+    const int64_t off = meta->off;
+    DOrf *orf = b.orf + meta->orf_off;
+    DGrp *grp = b.grp + meta->grp_off;
+    const uint32_t *linkF = b.linkF + off, *linkR = b.linkR + off;
+    uint8_t *cov = b.cov + off;
+    int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off, *nother = b.nother + meta->node_off;
+    uint32_t *nlink = b.nlink + meta->node_off;
+    double *no = b.no + meta->node_off;
+    // A. coverage by the longest ORF of every stop-group (functions.py:321-330)
+    for (int g = tid; g < meta->n_grp; g += NT) {
+        const DGrp G = grp[g];
+        const DOrf *r = &orf[G.orf_begin + G.n - 1];
+        int mi = r->start < r->stop ? r->start : r->stop;
+        int ma = r->start > r->stop ? r->start : r->stop;
+        if (ma > L - 1) ma = L - 1;
+        for (int n = mi; n < ma; n++) cov[n] = 1;
+    }
+    if (tid == 0) meta->n_bridge = 0;
+    __syncthreads();
+    // B. ordered sweep over positions: node ids, and "previous covered base" for the bridge test
+    int run = 0;
+    uint32_t lastcov = 0;
+    for (int base = 0; base < L; base += NT) {
+        const int i = base + tid;
+        uint32_t lf = 0, lr = 0, cv = 0;
+        if (i < L) { lf = linkF[i]; lr = linkR[i]; cv = cov[i] ? (uint32_t)i : 0u; }
+        uint32_t tot, mtot;
+        uint32_t ex = block_excl_scan<NT>((lf ? 1u : 0u) + (lr ? 1u : 0u), s_scan, &tot);
+        uint32_t pm = block_excl_max<NT>(cv, s_scan, &mtot);
+        if (pm < lastcov) pm = lastcov;
+        if (cv && (int)cv - (int)pm > 500) { // functions.py:334
+            int k = atomicAdd(&meta->n_bridge, 1);
+            if (k < PHX_MAX_BRIDGE) { meta->bridge[k].last = (int)pm; meta->bridge[k].base = (int)cv; }
+        }
+        int id = run + (int)ex;
+        if (lf) {
+            npos[id] = i + 1; nlink[id] = lf;
+            ninfo[id] = NINFO(LINK_KIND(lf) == LINK_START ? 0 : 1, i % 3 + 1);
+            if (LINK_KIND(lf) == LINK_START) orf[LINK_IDX(lf)].node = id; else grp[LINK_IDX(lf)].node = id;
+            id++;
+        }
+        if (lr) {
+            npos[id] = i + 1; nlink[id] = lr;
+            ninfo[id] = NINFO(LINK_KIND(lr) == LINK_START ? 0 : 1, -(i % 3 + 1));
+            if (LINK_KIND(lr) == LINK_START) orf[LINK_IDX(lr)].node = id; else grp[LINK_IDX(lr)].node = id;
+        }
+        run += (int)tot;
+        if (mtot > lastcov) lastcov = mtot;
+    }
+    const double pgap = contig_pstop(meta->gc, L);
+    if (tid == 0) {
+        npos[run] = 0; ninfo[run] = NINFO(2, 0); nlink[run] = 0; nother[run] = -1; no[run] = pgap;          // source, functions.py:440
+        npos[run + 1] = L + 1; ninfo[run + 1] = NINFO(3, 0); nlink[run + 1] = 0; nother[run + 1] = -1; no[run + 1] = pgap; // target
+        if (run + 2 != meta->n_node) meta->status = PHX_E_STATE; // n_node was sized as n_orf + n_grp + 2
+        if (meta->n_bridge > PHX_MAX_BRIDGE) meta->status = PHX_S_OVERFLOW;
+    }
+    __syncthreads();
+    // C. other_end[pos] (last writer wins, orfs.py:19-30) and the o1/o2 term (functions.py:373-384)
+    for (int v = tid; v < run; v += NT) {
+        const int q = npos[v] - 1;
+        const int fr = NFRAME(ninfo[v]);
+        const uint32_t lmine = fr > 0 ? linkF[q] : linkR[q];
+        const uint32_t lother = fr > 0 ? linkR[q] : linkF[q];
+        LinkInfo a = link_info(lmine, orf, grp);
+        int oe = a.val;
+        double o = pgap;
+        if (!lother) {
+            if (a.stop) o = orf[a.time].pstop; // longest ORF of the group
+        } else {
+            LinkInfo c = link_info(lother, orf, grp);
+            const bool other_wins = c.time > a.time;
+            if (other_wins) oe = c.val;
+            if (a.stop || c.stop) {
+                const LinkInfo sl = a.stop ? a : c; // the slot that makes `l in my_orfs` true
+                const LinkInfo st = a.stop ? c : a;
+                const DGrp G = grp[sl.idx];
+                int hit = -1;
+                for (int k = 0; k < G.n; k++)
+                    if (orf[G.orf_begin + k].start == oe) { hit = G.orf_begin + k; break; }
+                if (hit >= 0) o = orf[hit].pstop;        // get_orf(other_end[l], l)
+                else if (!st.stop) o = orf[st.idx].pstop; // get_orf(l, other_end[l])
+            }
+        }
+        nother[v] = oe;
+        no[v] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Edges, enumerated per destination node (CSR by destination).
+// score_gap functions.py:36-46, score_overlap functions.py:26-34.
+__device__ __forceinline__ double score_gap(int length, bool diff, double pgap) {
+    const double g = 1.0 - pgap;
+    if (length > 300) return pow(g, 100.0) + (double)length;
+    double s = 1.0 / pow(g, (double)length / 3.0);
+    if (diff) s += 20.0;
+    return s;
+}
+__device__ __forceinline__ double score_overlap(int length, bool diff, double pstop) {
+    double s = 1.0 / pow(1.0 - pstop, (double)length);
+    if (diff) s += 20.0;
+    return s;
+}
+
+struct EdgeSink {
+    uint32_t *esrc;
+    double *ew;
+    int n;
+};
+template <bool FILL>
+__device__ __forceinline__ void emit_edge(EdgeSink &s, int src, double w) {
+    if (FILL) { s.esrc[s.n] = (uint32_t)src; s.ew[s.n] = w; }
+    s.n++;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(NT) void k_edges(DBatch b) {
+    __shared__ uint32_t s_scan[NT / 64 + 1];
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0 || meta->n_node <= 0) {
+        if (!FILL && threadIdx.x == 0) meta->n_edge = 0;
+        return;
+    }
+    const int L = meta->L;
+    const int V = meta->n_node, ncds = V - 2, SRC = V - 2, TGT = V - 1;
+    const DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    const int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off, *nother = b.nother + meta->node_off;
+    const uint32_t *nlink = b.nlink + meta->node_off;
+    const double *no = b.no + meta->node_off;
+    uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x; // V+1 entries per contig
+    const double pgap = contig_pstop(meta->gc, L);
+    const int nbr = meta->n_bridge;
+    bool parallel = false;
+    uint32_t run_edges = 0;
+
+    for (int base = 0; base < V; base += NT) {
+        const int v = base + (int)threadIdx.x;
+        EdgeSink sink;
+        sink.n = 0;
+        if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
+        if (v < V && v != SRC) {
+            if (v == TGT) {
+                // functions.py:449-452
+                for (int u = ncds - 1; u >= 0 && L - npos[u] <= 2000; u--) {
+                    const int t = NTYPE(ninfo[u]), f = NFRAME(ninfo[u]);
+                    if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, score_gap(L - npos[u], false, pgap));
+                }
+            } else {
+                const int t = NTYPE(ninfo[v]), f = NFRAME(ninfo[v]), pos = npos[v];
+                const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
+                if (!open) {
+                    // ORF edges, functions.py:311-318
+                    if (t == 1) { // forward stop: one edge per start of the group
+                        const DGrp G = grp[LINK_IDX(nlink[v])];
+                        for (int k = 0; k < G.n; k++) emit_edge<FILL>(sink, orf[G.orf_begin + k].node, orf[G.orf_begin + k].weight);
+                    } else { // reverse start: from the group's stop node
+                        const DOrf *r = &orf[LINK_IDX(nlink[v])];
+                        emit_edge<FILL>(sink, grp[r->grp].node, r->weight);
+                    }
+                } else {
+                    const int my_other = nother[v];
+                    const double my_o = no[v];
+                    if (pos <= 2000) emit_edge<FILL>(sink, SRC, score_gap(pos, false, pgap)); // functions.py:445-448
+                    // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
+                    for (int u = v - 1; u >= 0; u--) {
+                        const int d = pos - npos[u];
+                        if (d >= 500) break;
+                        if (d <= 0) continue;
+                        const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
+                        if (t == 0) { // v = forward start
+                            if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, score_gap(d - 3, false, pgap));
+                            else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, score_gap(d - 3, true, pgap));
+                        } else { // v = reverse stop
+                            if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, score_gap(d - 3, false, pgap));
+                            else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, score_gap(d - 3, true, pgap));
+                        }
+                    }
+                    // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
+                    for (int u = v + 1; u < ncds; u++) {
+                        const int r = npos[u];
+                        const int d = r - pos;
+                        if (d >= 500) break;
+                        if (d <= 0) continue;
+                        const int rt = NTYPE(ninfo[u]), rf = NFRAME(ninfo[u]);
+                        const int r_other = nother[u];
+                        const double ps = (my_o + no[u]) / 2.0; // ave([o1,o2]), functions.py:385
+                        if (t == 1) { // v = reverse stop (l), lf < 0
+                            if (rt == 0 && rf < 0) { // same strand: right is a reverse start
+                                if (f != rf && r < my_other && r_other < pos) emit_edge<FILL>(sink, u, score_overlap(d + 3, false, ps));
+                            } else if (rt == 1 && rf > 0) { // right is a forward stop
+                                if (r_other + 3 < pos && r < my_other) emit_edge<FILL>(sink, u, score_overlap(d + 3, true, ps));
+                            }
+                        } else { // v = forward start (l), lf > 0
+                            if (rt == 1 && rf > 0) { // same strand: right is a forward stop
+                                if (f != rf && r < my_other && r_other < pos) emit_edge<FILL>(sink, u, score_overlap(d + 3, false, ps));
+                            } else if (rt == 0 && rf < 0) { // right is a reverse start
+                                if (r_other < pos && r < my_other) emit_edge<FILL>(sink, u, score_overlap(d + 3, true, ps));
+                            }
+                        }
+                    }
+                    // long non-coding bridges, functions.py:334-354 (v as right node)
+                    for (int k = 0; k < nbr && k < PHX_MAX_BRIDGE; k++) {
+                        const int last = meta->bridge[k].last, bs = meta->bridge[k].base;
+                        if (!(bs - 1 <= pos && pos < bs + 500)) continue;
+                        // left nodes with last-500 < l <= last+1 : binary search the first pos > last-500
+                        int lo = 0, hi = ncds;
+                        while (lo < hi) { int m = (lo + hi) >> 1; if (npos[m] > last - 500) hi = m; else lo = m + 1; }
+                        for (int u = lo; u < ncds && npos[u] <= last + 1; u++) {
+                            const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
+                            const int d = pos - npos[u];
+                            bool hit = false, diff = false;
+                            if (t == 0) { // v forward start
+                                if (lt == 1 && lf > 0) hit = true;
+                                else if (lt == 0 && lf < 0) { hit = true; diff = true; }
+                            } else { // v reverse stop
+                                if (lt == 0 && lf < 0) hit = true;
+                                else if (lt == 1 && lf > 0) { hit = true; diff = true; }
+                            }
+                            if (hit) {
+                                if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
+                                emit_edge<FILL>(sink, u, score_gap(d - 3, diff, pgap));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!FILL) {
+            uint32_t tot;
+            uint32_t ex = block_excl_scan<NT>((uint32_t)sink.n, s_scan, &tot);
+            if (v < V) in_off[v] = run_edges + ex;
+            run_edges += tot; // block-uniform
+        }
+    }
+    if (!FILL && threadIdx.x == 0) { in_off[V] = run_edges; meta->n_edge = (int)run_edges; }
+    if (parallel) atomicMin(&meta->status, PHX_S_PARALLEL);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact integers for the path sums: NL little-endian 64-bit limbs, two's complement.
+template <int NL>
+struct WInt {
+    uint64_t v[NL];
+};
+#define WINF_TOP 0x7fffffffffffffffull
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_inf() {
+    WInt<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) r.v[i] = 0;
+    r.v[NL - 1] = WINF_TOP;
+    return r;
+}
+template <int NL>
+__device__ __forceinline__ bool wi_is_inf(const WInt<NL> &a) { return a.v[NL - 1] == WINF_TOP; }
+// x is integer-valued (result of trunc()); |x| < 2^(64*NL-2) is guaranteed by the caller's choice of NL
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_from_double(double x) {
+    WInt<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = 0;
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    const int ef = (int)((bits >> 52) & 0x7ff);
+    if (ef != 0) {
+        uint64_t m = (bits & 0xfffffffffffffull) | (1ull << 52);
+        const int e = ef - 1075; // value = m * 2^e
+        if (e <= 0) {
+            if (e > -64) r.v[0] = m >> (-e);
+        } else {
+            const int w = e >> 6, s = e & 63;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                if (i == w) r.v[i] |= m << s;
+                if (i == w + 1 && s) r.v[i] |= m >> (64 - s);
+            }
+        }
+        if (bits >> 63) { // negate
+            uint64_t c = 1;
+#pragma unroll
+            for (int i = 0; i < NL; i++) { uint64_t t = ~r.v[i] + c; c = (c && t == 0) ? 1 : 0; r.v[i] = t; }
+        }
+    }
+    return r;
+}
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_add(const WInt<NL> &a, const WInt<NL> &b) {
+    WInt<NL> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint64_t s = a.v[i] + b.v[i];
+        uint64_t c1 = s < a.v[i];
+        uint64_t s2 = s + c;
+        uint64_t c2 = s2 < s;
+        r.v[i] = s2;
+        c = c1 | c2;
+    }
+    return r;
+}
+template <int NL>
+__device__ __forceinline__ bool wi_lt(const WInt<NL> &a, const WInt<NL> &b) { // signed a < b
+    if (a.v[NL - 1] != b.v[NL - 1]) return (int64_t)a.v[NL - 1] < (int64_t)b.v[NL - 1];
+#pragma unroll
+    for (int i = NL - 2; i >= 0; i--)
+        if (a.v[i] != b.v[i]) return a.v[i] < b.v[i];
+    return false;
+}
+template <int NL>
+__device__ __forceinline__ bool wi_eq(const WInt<NL> &a, const WInt<NL> &b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < NL; i++) e = e && a.v[i] == b.v[i];
+    return e;
+}
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_load(const uint64_t *p) {
+    WInt<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = p[i];
+    return r;
+}
+template <int NL>
+__device__ __forceinline__ void wi_store(uint64_t *p, const WInt<NL> &a) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) p[i] = a.v[i];
+}
+
+// Shortest path source -> target with exact integer weights trunc(w*1000) (edges.py:22; fastpathz keeps
+// the integer part).  The graph is not a DAG: nodes are relaxed in position order in chunks of
+// NT, each chunk iterated (Jacobi inside the chunk, so the result is schedule-independent) until stable,
+// and the sweep over chunks is repeated until a sweep changes nothing.  The fixed point of min-plus
+// relaxation is the unique exact distance vector; ties between equal-length paths are broken by the
+// in-edge order (first minimal in-edge wins), see DESIGN.md.
+template <int NL>
+__global__ __launch_bounds__(NT) void k_sssp(DBatch b) {
+    __shared__ int s_flag[2];
+    DMeta *meta = &b.meta[blockIdx.x];
+    const int V = meta->n_node;
+    if (meta->status < 0 || V <= 2) {
+        if (threadIdx.x == 0) meta->sweeps = 0;
+        return;
+    }
+    const int SRC = V - 2;
+    const uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
+    const uint32_t *esrc = b.esrc + meta->edge_off;
+    const double *ew = b.ew + meta->edge_off;
+    const uint64_t *ewl = b.ewl ? b.ewl + (size_t)meta->edge_off * NL : nullptr; // phx_solve: integer weights given as limbs
+    uint64_t *dist = b.dist + (size_t)meta->node_off * NL;
+    int32_t *parent = b.parent + meta->node_off;
+    const int tid = threadIdx.x;
+    for (int v = tid; v < V; v += NT) {
+        WInt<NL> d = wi_inf<NL>();
+        if (v == SRC) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) d.v[i] = 0;
+        }
+        wi_store<NL>(dist + (size_t)v * NL, d);
+        parent[v] = -1;
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    __syncthreads();
+    const int nchunk = (V + NT - 1) / NT;
+    int sweeps = 0, it = 0;
+    bool any = true, bad = false;
+    while (any && !bad) {
+        any = false;
+        for (int c = 0; c < nchunk; c++) {
+            const int v = c * NT + tid;
+            int inner = 0;
+            bool chg = true;
+            while (chg) {
+                bool improved = false;
+                WInt<NL> best;
+                int bp = -1;
+                if (v < V && v != SRC) {
+                    best = wi_load<NL>(dist + (size_t)v * NL);
+                    const uint32_t e0 = in_off[v], e1 = in_off[v + 1];
+                    for (uint32_t e = e0; e < e1; e++) {
+                        const uint32_t u = esrc[e];
+                        const WInt<NL> du = wi_load<NL>(dist + (size_t)u * NL);
+                        if (wi_is_inf<NL>(du)) continue;
+                        const WInt<NL> w = ewl ? wi_load<NL>(ewl + (size_t)e * NL) : wi_from_double<NL>(trunc(ew[e] * 1000.0));
+                        const WInt<NL> cand = wi_add<NL>(du, w);
+                        if (wi_lt<NL>(cand, best)) { best = cand; bp = (int)u; }
+                    }
+                    improved = bp >= 0;
+                }
+                __syncthreads(); // every read of this iteration is done
+                if (improved) {
+                    wi_store<NL>(dist + (size_t)v * NL, best);
+                    parent[v] = bp;
+                    s_flag[it & 1] = 1;
+                }
+                if (tid == 0) s_flag[(it + 1) & 1] = 0;
+                __syncthreads();
+                chg = s_flag[it & 1] != 0;
+                it++;
+                any = any || chg;
+                if (++inner > NT + 8) { bad = true; break; } // a chunk of NT nodes converges in <= NT rounds unless a cycle is negative
+            }
+            if (bad) break;
+        }
+        if (++sweeps > V + 2) bad = true;
+    }
+    if (tid == 0) {
+        meta->sweeps = sweeps;
+        if (bad) meta->status = PHX_S_NEGCYCLE;
+    }
+}
+
+// Path -> genes (phanotate.py:65-76, locus.py:29-37).  One thread per contig.
+template <int NL>
+__global__ void k_path(DBatch b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.n_contig) return;
+    DMeta *meta = &b.meta[c];
+    meta->n_genes = 0; meta->n_path = 0; meta->gene_off = 0;
+    const int V = meta->n_node;
+    if (meta->status < 0 || V <= 2) return; // phanotate.py:63: len(graph) > 2
+    const int SRC = V - 2, TGT = V - 1;
+    const uint64_t *dist = b.dist + (size_t)meta->node_off * NL;
+    const int32_t *parent = b.parent + meta->node_off;
+    const int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
+    const uint32_t *nlink = b.nlink + meta->node_off;
+    const DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    int32_t *path = b.path + meta->node_off;
+    if (dist[(size_t)TGT * NL + NL - 1] == WINF_TOP) { meta->status = PHX_S_NOPATH; return; }
+    int n = 0;
+    for (int v = TGT; v != SRC && n <= V; v = parent[v]) n++;
+    if (n > V) { meta->status = PHX_S_NEGCYCLE; return; }
+    {
+        int k = n;
+        for (int v = TGT; k >= 0; v = parent[v]) { path[k--] = v; if (v == SRC) break; }
+    }
+    meta->n_path = n + 1;
+    const int npairs = n / 2; // shortest_path[1:] taken two at a time (file_handling.pairwise)
+    const uint32_t g0 = atomicAdd(b.gene_total, (uint32_t)npairs);
+    meta->gene_off = g0;
+    meta->n_genes = npairs;
+    for (int i = 0; i < npairs; i++) {
+        const int a = path[2 * i + 1], bb = path[2 * i + 2];
+        DGene g;
+        g.left = npos[a];
+        g.right = npos[bb] + 2; // locus.py:30
+        g.frame = NFRAME(ninfo[a]);
+        g.strand = g.frame < 0 ? -1 : 1;
+        double w = 0.0; // Graph.weight, graphs.py:91-96
+        const int ta = NTYPE(ninfo[a]);
+        if (ta == 0 && g.frame > 0 && LINK_KIND(nlink[a]) == LINK_START) {
+            const DOrf *r = &orf[LINK_IDX(nlink[a])];
+            if (grp[r->grp].node == bb) w = r->weight;
+        } else if (ta == 1 && g.frame < 0 && LINK_KIND(nlink[bb]) == LINK_START) {
+            const DOrf *r = &orf[LINK_IDX(nlink[bb])];
+            if (grp[r->grp].node == a) w = r->weight;
+        }
+        g.score = w;
+        b.genes[g0 + i] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+extern "C" {
+void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
+    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles);
+}
+void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_train(const DBatch *, void *) {}
+void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_nodes(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_nodes, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_sssp(const DBatch *b, int nl, void *stream) {
+    dim3 g(b->n_contig), t(NT);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nl) {
+    case 2: hipLaunchKernelGGL(k_sssp<2>, g, t, 0, s, *b); break;
+    case 4: hipLaunchKernelGGL(k_sssp<4>, g, t, 0, s, *b); break;
+    case 8: hipLaunchKernelGGL(k_sssp<8>, g, t, 0, s, *b); break;
+    default: hipLaunchKernelGGL(k_sssp<17>, g, t, 0, s, *b); break;
+    }
+}
+void phxk_path(const DBatch *b, int nl, void *stream) {
+    dim3 g((b->n_contig + 63) / 64), t(64);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nl) {
+    case 2: hipLaunchKernelGGL(k_path<2>, g, t, 0, s, *b); break;
+    case 4: hipLaunchKernelGGL(k_path<4>, g, t, 0, s, *b); break;
+    case 8: hipLaunchKernelGGL(k_path<8>, g, t, 0, s, *b); break;
+    default: hipLaunchKernelGGL(k_path<17>, g, t, 0, s, *b); break;
+    }
+}
+}
