@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — Mbp/s annotated on synthetic 50 kb phage contigs (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path (libphx phx_run: features -> ORF scan -> scoring ->
+graph -> exact shortest path -> genes) over one batch of synthetic contigs that is already
+resident in HBM.  Weak scaling: every rank (= one GPU) owns its own batch of --contigs contigs
+(seeds disjoint per rank); there is no data-path collective — contigs are independent
+(phanotate.py:40,56) — only the barrier / max-over-ranks around the timed region.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(sz):
+    """B_algo = L/4 + 4 L + 64 N_orf + 32 E + 64 V for the whole batch."""
+    return sz["L"] / 4.0 + 4.0 * sz["L"] + 64.0 * sz["n_orf"] + 32.0 * sz["n_edge"] + 64.0 * sz["n_node"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--contigs", type=int, default=1000, help="contigs per GPU (BASELINE config 4: 1000 x 50 kb on 1 GPU)")
+    ap.add_argument("--length", type=int, default=50000)
+    ap.add_argument("--cpu-contigs", type=int, default=64, help="size of the bounded sample timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import phanotate_amd as pa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d; launch with torch.distributed.run for N>1\n" % (world, args.gpus))
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: no GPU visible; libphx has no CPU path\n")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # synthetic contigs: rank r owns seeds r*C .. r*C+C-1
+    C_, L_ = args.contigs, args.length
+    seqs = [pa.synth_contig(rank * C_ + i, L_) for i in range(C_)]
+    stream = torch.cuda.current_stream().cuda_stream
+    ann = pa.Annotator(device=local_rank, stream=stream)
+
+    # PCIe-inclusive pass (H2D + kernels + D2H), reported on stderr only — never `value`
+    t0 = time.perf_counter()
+    res = ann.annotate(seqs)
+    t_e2e = time.perf_counter() - t0
+    n_genes = sum(len(g) for _, g in res)
+    n_bad = sum(1 for st, _ in res if st < 0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ann.run()
+    ann.set_profiling(True)
+    ann.stage_ms(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ann.run()
+    barrier()
+    dt = time.perf_counter() - t0
+    ann.set_profiling(False)
+    stages = ann.stage_ms(reset=True)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sz = ann.batch_sizes()
+    bp_total = float(sz["L"]) * world  # every rank holds the same amount of bases
+    value = bp_total * args.steps / dt / 1e6
+
+    if rank == 0:
+        kernels = {k: v for k, v in stages.items() if k not in ("copies", "memset") and v[1] > 0}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms = kernels[dom][0] / kernels[dom][1]
+        balgo = algorithmic_bytes(sz)
+        achieved = balgo / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mbp/s annotated (whole node) on 50 kb synthetic phage contigs",
+            "value": round(value, 3),
+            "unit": "Mbp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int128 (fp64 edge weights)",
+            "data": "synthetic",
+            "config": {
+                "workload": "batch of %d synthetic %d bp phage contigs per GPU, resident in HBM (BASELINE config 4)" % (C_, L_),
+                "contigs_per_gpu": C_,
+                "contig_length": L_,
+                "sharding": "per-contig across %d GPU(s), no collective in the data path" % world,
+                "genes_called_rank0": n_genes,
+                "contigs_with_error_status": n_bad,
+                "int_limbs": int(ann.globals(0).n_limbs),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": int(balgo),
+                "avg_launch_ms": round(dom_ms, 4),
+            },
+            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[1] > 0},
+            "pcie_inclusive_Mbp_s": round(float(sz["L"]) / t_e2e / 1e6, 3),
+        }
+        if not args.no_cpu and world == 1:
+            from oracle import oracle
+
+            ns = max(1, min(args.cpu_contigs, C_))
+            oracle.lib()
+            t0 = time.perf_counter()
+            for i in range(ns):
+                r = oracle.run(seqs[i])
+                assert r["status"] == 0
+            tc = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": round(ns * L_ / tc / 1e6, 4),
+                "unit": "Mbp/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "first %d of the %d contigs of this batch, C oracle (oracle/phx_oracle.c), %.1f s" % (ns, C_, tc),
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ann.close()
+
+
+if __name__ == "__main__":
+    main()
