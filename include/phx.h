@@ -74,7 +74,7 @@ typedef struct phx_gene {
 typedef struct phx_result {
     int32_t status;  /* PHX_S_* */
     int32_t n_genes;
-    phx_gene *genes; /* library-owned; in path order == ascending left coordinate */
+    phx_gene *genes; /* library-owned; in path order (ascending right coordinate), as phanotate.py:71-76 adds them */
 } phx_result;
 
 /* ---- stage-tap records (parity tests; layout is part of the ABI) ---- */

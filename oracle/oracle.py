@@ -87,6 +87,8 @@ def lib():
         _lib.orc_run.restype = C.c_int
         _lib.orc_free.argtypes = [C.POINTER(Result)]
         _lib.orc_sizeof_params.restype = C.c_size_t
+        _lib.orc_score_rbs.argtypes = [C.c_char_p, C.c_int]
+        _lib.orc_score_rbs.restype = C.c_int
         _lib.orc_sizeof_result.restype = C.c_size_t
         assert _lib.orc_sizeof_params() == C.sizeof(Params)
         assert _lib.orc_sizeof_result() == C.sizeof(Result)
@@ -162,3 +164,10 @@ def run(seq, params=None, stages=3):
             out["gene_strand"], out["gene_score"] = ge["strand"].astype(np.int8), ge["score"]
     lib().orc_free(C.byref(r))
     return out
+
+
+def score_rbs(seq):
+    """functions.score_rbs on one window (<= 21 characters)."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    return lib().orc_score_rbs(seq, len(seq))

@@ -54,6 +54,32 @@ class PhxError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  libphx.so needs `libamdhip64.so.7`; the PyTorch-ROCm wheel ships its
+    own copy with the same soname, loaded by path from torch/lib.  If libphx pulled in /opt/rocm's copy
+    first and torch its own later, two runtimes would fight over the device (torch then fails to
+    initialise) and stream / pointer handles would not be interchangeable.  So when a torch install is
+    present, its runtime is mapped first and libphx binds to it by soname; without torch the system
+    ROCm runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # already mapped by torch
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libphx.so.  Raises if the HIP extension has not been built — the product never falls back."""
     global _lib
@@ -62,6 +88,7 @@ def lib():
     if not os.path.exists(SO):
         raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C phanotate_amd/csrc`; phanotate_amd has no CPU fallback" % SO)
+    _preload_hip_runtime()
     L = C.CDLL(SO)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     P = C.POINTER
