@@ -117,6 +117,7 @@ typedef struct phx_globals {
     int32_t n_orf, n_group, n_node, n_edge, n_bridge;
     int32_t n_limbs;     /* 64-bit limbs of the integer kernel that solved this batch */
     int32_t sssp_sweeps; /* outer sweeps of the device relaxation */
+    int32_t sssp_iters;  /* relaxation rounds summed over all windows and sweeps */
     int32_t status;
 } phx_globals;
 

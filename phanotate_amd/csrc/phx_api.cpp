@@ -32,6 +32,8 @@ struct phx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // side streams so that independent SSSP classes overlap
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -46,13 +48,15 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_gcc, b_cnt, b_cov, b_rbs, b_linkF, b_linkR, b_orf, b_grp;
+    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_gcc, b_cnt, b_cov, b_rbs, b_linkF, b_linkR, b_orf, b_grp, b_bits, b_item;
+    int64_t tot_words = 0, tot_items = 0;
     DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot;
     void *h_stage = nullptr; // pinned staging for H2D of ASCII
     size_t h_stage_cap = 0;
     std::vector<DGene> h_genes;
     // profiling
     bool prof = false;
+    bool force_global_sssp = false; // test hook: run every contig through the global-memory SSSP kernel
     float stage_ms[PHX_N_STAGES] = {0};
     int stage_n[PHX_N_STAGES] = {0};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -195,11 +199,13 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->cls = (uint8_t *)c->b_cls.p; b->gcc = (uint8_t *)c->b_gcc.p; b->cnt = (uint8_t *)c->b_cnt.p; b->cov = (uint8_t *)c->b_cov.p;
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->linkF = (uint32_t *)c->b_linkF.p; b->linkR = (uint32_t *)c->b_linkR.p;
+    b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
     b->npos = (int32_t *)c->b_npos.p; b->ninfo = (int32_t *)c->b_ninfo.p; b->nother = (int32_t *)c->b_nother.p; b->parent = (int32_t *)c->b_parent.p;
     b->nlink = (uint32_t *)c->b_nlink.p; b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
     b->dist = (uint64_t *)c->b_dist.p;
+    b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
@@ -211,7 +217,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->n = n;
     c->meta.assign((size_t)n, DMeta());
     c->tiles.clear();
-    int64_t off = 0;
+    int64_t off = 0, words = 0, items = 0;
     for (int i = 0; i < n; i++) {
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
@@ -219,9 +225,14 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         memset(&m, 0, sizeof(m));
         m.off = offsets_or_null ? offsets_or_null[i] : off;
         m.L = (int32_t)L;
-        for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) c->tiles.push_back(DTile{i, (int32_t)p0});
+        int nt = 0;
+        for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) { c->tiles.push_back(DTile{i, (int32_t)p0}); nt++; }
+        m.nw = 8 * nt; // every feature tile writes 8 words per (class, frame)
+        m.bits_off = words; m.item_off = items;
+        words += 12 * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
         off += L;
     }
+    c->tot_words = words; c->tot_items = items;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
     c->uploaded = true;
     c->ran = false;
@@ -241,6 +252,8 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
+    if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
+    if ((rc = ensure(c, c->b_item, (size_t)(c->tot_items + 8) * 8))) return rc;
     return PHX_OK;
 }
 
@@ -310,6 +323,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
     phx_ctx *c = new phx_ctx();
     c->device = device;
     c->params = *params;
+    c->force_global_sssp = getenv("PHX_FORCE_GLOBAL_SSSP") != nullptr; // test hook
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
@@ -317,6 +331,9 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         c->own_stream = true;
     }
+    for (int a = 0; a < 3; a++)
+        if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
@@ -335,7 +352,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_gcc, &c->b_cnt, &c->b_cov, &c->b_rbs, &c->b_linkF, &c->b_linkR, &c->b_orf, &c->b_grp,
+    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_gcc, &c->b_cnt, &c->b_cov, &c->b_rbs, &c->b_linkF, &c->b_linkR, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot};
     for (DevBuf *b : all) release(*b);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -346,6 +363,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int a = 0; a < 3; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -393,7 +412,11 @@ int phx_run(phx_ctx *c) {
     hipStream_t s = c->stream;
     const size_t T = (size_t)c->totalL;
     // reset per-contig accumulators (offsets and lengths stay)
-    for (DMeta &m : c->meta) { int64_t off = m.off; int32_t L = m.L; memset(&m, 0, sizeof(m)); m.off = off; m.L = L; }
+    for (DMeta &m : c->meta) {
+        DMeta k = m;
+        memset(&m, 0, sizeof(m));
+        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off;
+    }
     DBatch b;
     {
         StageTimer t(c, ST_MEMSET);
@@ -452,35 +475,57 @@ int phx_run(phx_ctx *c) {
     }
     HIPCHK(c, hipStreamSynchronize(s));
     int64_t e = 0;
-    int need_bits = 0;
+    int nlmax = 2;
+    struct Cls { bool any = false; size_t lds = 0; } cls[4][3]; // [limb class][mode]
+    const int nl_of[4] = {2, 4, 8, 17};
     for (DMeta &m : c->meta) {
         m.edge_off = e;
+        m.sssp_nl = 2; m.sssp_mode = 0;
         if (m.status < 0) { m.n_edge = 0; continue; }
         e += m.n_edge;
         // |dist| <= V * max|w|: bits = maxexp + ceil(log2 V) + sign + one spare bit below the INF pattern
-        int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
-        need_bits = std::max(need_bits, bits);
+        const int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
+        int k = bits <= 128 ? 0 : bits <= 256 ? 1 : bits <= 512 ? 2 : 3;
+        if (bits > 17 * 64) { m.status = PHX_S_OVERFLOW; continue; }
+        m.sssp_nl = nl_of[k];
+        nlmax = std::max(nlmax, m.sssp_nl);
+        const size_t lds = phxk_sssp_lds_bytes(m.n_node, m.sssp_nl);
+        m.sssp_mode = c->force_global_sssp ? 0 : lds <= 79 * 1024 ? 1 : lds <= 158 * 1024 ? 2 : 0;
+        if (m.n_node > 2) { cls[k][m.sssp_mode].any = true; cls[k][m.sssp_mode].lds = std::max(cls[k][m.sssp_mode].lds, lds); }
     }
     c->tot_edge = e;
-    int nl = need_bits <= 128 ? 2 : need_bits <= 256 ? 4 : need_bits <= 512 ? 8 : 17;
-    if (need_bits > 17 * 64) {
-        for (DMeta &m : c->meta) {
-            int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
-            if (m.status >= 0 && bits > 17 * 64) m.status = PHX_S_OVERFLOW;
-        }
-    }
-    c->n_limbs = nl;
+    c->n_limbs = nlmax;
     if ((rc = ensure(c, c->b_esrc, (size_t)(e + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_ew, (size_t)(e + 1) * 8))) return rc;
-    if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)nl))) return rc;
+    if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)nlmax))) return rc;
     {
         StageTimer t(c, ST_COPY);
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
-    { StageTimer t(c, ST_SSSP); phxk_sssp(&b, nl, s); }
-    { StageTimer t(c, ST_PATH); phxk_path(&b, nl, s); }
+    {
+        // one launch per (limb class, memory mode) that occurs in the batch; the launches are independent
+        // (disjoint contigs), so all but the first go to side streams and overlap
+        StageTimer t(c, ST_SSSP);
+        int nlaunch = 0;
+        bool forked = false, used[3] = {false, false, false};
+        for (int k = 0; k < 4; k++)
+            for (int mode = 2; mode >= 0; mode--) // largest-LDS class first: it has the fewest workgroups per CU
+                if (cls[k][mode].any) {
+                    hipStream_t st = s;
+                    if (nlaunch > 0 && c->aux[0]) {
+                        const int a = (nlaunch - 1) % 3;
+                        if (!forked) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); forked = true; }
+                        if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
+                        st = c->aux[a];
+                    }
+                    phxk_sssp(&b, nl_of[k], mode, cls[k][mode].lds, st);
+                    nlaunch++;
+                }
+        for (int a = 0; a < 3; a++)
+            if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
+    }
     HIPCHK(c, hipGetLastError());
     { // sync #3: statuses, gene counts
         StageTimer t(c, ST_COPY);
@@ -488,6 +533,8 @@ int phx_run(phx_ctx *c) {
     }
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
+    if (getenv("PHX_DEBUG_SSSP"))
+        for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pad2 * 0.01);
     c->ran = true;
     return PHX_OK;
 }
@@ -542,6 +589,9 @@ void phx_free_results(phx_result *res, int32_t n) {
     HIPCHK(c, hipSetDevice((c)->device));                             \
     const DMeta &m = (c)->meta[(size_t)(contig)];
 
+extern "C" void phxk_sssp_only(const DBatch *b, int n_limbs, void *stream);
+static void hipLaunchSsspOnly(const DBatch *b, int nl, hipStream_t s) { phxk_sssp_only(b, nl, (void *)s); }
+
 static double host_contig_pstop(uint32_t gc, int L) {
     double fa = (double)((uint32_t)L - gc), fg = (double)gc, d = (double)((int64_t)L * 2);
     double Pa = fa / d, Pt = fa / d, Pg = fg / d;
@@ -554,7 +604,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     memset(out, 0, sizeof(*out));
     out->L = m.L;
     out->status = m.status;
-    out->n_limbs = c->n_limbs;
+    out->n_limbs = m.sssp_nl;
     if (m.status < 0) return PHX_OK;
     out->pstop = host_contig_pstop(m.gc, m.L);
     double bgs = 0, trs = 0;
@@ -568,6 +618,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     for (int i = 0; i < 4; i++) { out->pos_max[i] /= ymx; out->pos_min[i] /= ymn; }
     out->n_orf = m.n_orf; out->n_group = m.n_grp; out->n_node = m.n_node; out->n_edge = m.n_edge; out->n_bridge = m.n_bridge;
     out->sssp_sweeps = m.sweeps;
+    out->sssp_iters = m.sssp_iters;
     return PHX_OK;
 }
 
@@ -584,26 +635,45 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
     return PHX_OK;
 }
 
+// Reference insertion order of the stop-groups = ascending DGrp.evkey.  ref_rank[g] = rank of device
+// group g, ref_first[g] = number of ORFs in the groups before it.
+static void reference_order(const std::vector<DGrp> &grp, std::vector<int> &order, std::vector<int> &ref_rank, std::vector<int> &ref_first) {
+    const size_t G = grp.size();
+    order.resize(G); ref_rank.resize(G); ref_first.resize(G);
+    for (size_t g = 0; g < G; g++) order[g] = (int)g;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return grp[(size_t)a].evkey < grp[(size_t)b].evkey; });
+    int acc = 0;
+    for (size_t r = 0; r < G; r++) { ref_rank[(size_t)order[r]] = (int)r; ref_first[(size_t)order[r]] = acc; acc += grp[(size_t)order[r]].n; }
+}
+
 int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
     TAP_PRE(c, contig);
     if (m.status < 0 || m.n_orf == 0) return PHX_OK;
     if (!out) return PHX_E_ARG;
     std::vector<DOrf> d((size_t)m.n_orf);
+    std::vector<DGrp> grp((size_t)m.n_grp);
     HIPCHK(c, hipMemcpy(d.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * d.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(grp.data(), (DGrp *)c->b_grp.p + m.grp_off, sizeof(DGrp) * grp.size(), hipMemcpyDeviceToHost));
+    std::vector<int> order, ref_rank, ref_first;
+    reference_order(grp, order, ref_rank, ref_first);
     phx_globals gl;
     phx_tap_globals(c, contig, &gl);
-    for (size_t k = 0; k < d.size(); k++) {
-        const DOrf &r = d[k];
-        phx_orf &o = out[k];
-        o.start = r.start; o.stop = r.stop; o.frame = r.frame;
-        o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
-        o.rbs = r.rbs; o.startidx = r.startidx; o.group = r.grp;
-        double S = 0;
-        for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = r.hist[a * 3 + cc]; S += (double)r.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
-        o.S = S;
-        o.pstop = r.pstop;
-        o.weight_rbs = gl.training_rbs[r.rbs] / gl.background_rbs[r.rbs];
-        o.weight = r.weight;
+    size_t k = 0;
+    for (size_t rr = 0; rr < order.size(); rr++) {
+        const DGrp &G = grp[(size_t)order[rr]];
+        for (int j = 0; j < G.n; j++, k++) {
+            const DOrf &r = d[(size_t)(G.orf_begin + j)];
+            phx_orf &o = out[k];
+            o.start = r.start; o.stop = r.stop; o.frame = r.frame;
+            o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
+            o.rbs = r.rbs; o.startidx = r.startidx; o.group = (int32_t)rr;
+            double S = 0;
+            for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = r.hist[a * 3 + cc]; S += (double)r.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
+            o.S = S;
+            o.pstop = r.pstop;
+            o.weight_rbs = gl.training_rbs[r.rbs] / gl.background_rbs[r.rbs];
+            o.weight = r.weight;
+        }
     }
     return PHX_OK;
 }
@@ -625,6 +695,8 @@ int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
     HIPCHK(c, hipMemcpy(no.data(), (double *)c->b_no.p + m.node_off, V * 8, hipMemcpyDeviceToHost));
     if (m.n_grp) HIPCHK(c, hipMemcpy(grp.data(), (DGrp *)c->b_grp.p + m.grp_off, sizeof(DGrp) * grp.size(), hipMemcpyDeviceToHost));
     if (m.n_orf) HIPCHK(c, hipMemcpy(orf.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * orf.size(), hipMemcpyDeviceToHost));
+    std::vector<int> order, ref_rank, ref_first;
+    reference_order(grp, order, ref_rank, ref_first);
     for (size_t v = 0; v < V; v++) {
         out[v].pos = npos[v]; out[v].type = (int8_t)NTYPE(ninfo[v]); out[v].frame = (int8_t)NFRAME(ninfo[v]); out[v].pad = 0;
         out[v].other = nother[v]; out[v].o = no[v];
@@ -633,14 +705,14 @@ int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
         if (v + 2 == V) ref = m.n_orf + m.n_grp;
         else if (v + 1 == V) ref = m.n_orf + m.n_grp + 1;
         else if (LINK_KIND(nlink[v]) == LINK_STOP) {
-            const int g = (int)LINK_IDX(nlink[v]);
-            ref = grp[(size_t)g].orf_begin + g + (grp[(size_t)g].frame > 0 ? 1 : 0);
+            const size_t g = (size_t)LINK_IDX(nlink[v]);
+            ref = ref_first[g] + ref_rank[g] + (grp[g].frame > 0 ? 1 : 0);
         } else {
             const int k = (int)LINK_IDX(nlink[v]);
-            const int g = orf[(size_t)k].grp;
-            const int mth = k - grp[(size_t)g].orf_begin;
-            const int base = grp[(size_t)g].orf_begin + g;
-            ref = grp[(size_t)g].frame > 0 ? (mth == 0 ? base : base + 1 + mth) : base + 1 + mth;
+            const size_t g = (size_t)orf[(size_t)k].grp;
+            const int mth = k - grp[g].orf_begin;
+            const int base = ref_first[g] + ref_rank[g];
+            ref = grp[g].frame > 0 ? (mth == 0 ? base : base + 1 + mth) : base + 1 + mth;
         }
         out[v].refidx = ref;
     }
@@ -672,9 +744,9 @@ int phx_tap_path(phx_ctx *c, int32_t contig, int32_t *path, int32_t cap, int32_t
         HIPCHK(c, hipMemcpy(path, (int32_t *)c->b_path.p + m.node_off, (size_t)m.n_path * 4, hipMemcpyDeviceToHost));
     }
     if (dist_limbs) {
-        if (cap_limbs < c->n_limbs) return PHX_E_ARG;
-        const size_t tgt = (size_t)m.node_off + (size_t)m.n_node - 1;
-        HIPCHK(c, hipMemcpy(dist_limbs, (uint64_t *)c->b_dist.p + tgt * (size_t)c->n_limbs, (size_t)c->n_limbs * 8, hipMemcpyDeviceToHost));
+        if (cap_limbs < m.sssp_nl) return PHX_E_ARG;
+        const size_t tgt = (size_t)m.node_off * (size_t)c->n_limbs + ((size_t)m.n_node - 1) * (size_t)m.sssp_nl;
+        HIPCHK(c, hipMemcpy(dist_limbs, (uint64_t *)c->b_dist.p + tgt, (size_t)m.sssp_nl * 8, hipMemcpyDeviceToHost));
     }
     return PHX_OK;
 }
@@ -712,7 +784,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     }
     DMeta m;
     memset(&m, 0, sizeof(m));
-    m.n_node = V; m.n_edge = E; m.L = 1;
+    m.n_node = V; m.n_edge = E; m.L = 1; m.sssp_nl = n_limbs; m.sssp_mode = 0;
     int rc;
     DevBuf &b_meta = c->b_meta;
     if ((rc = ensure(c, b_meta, sizeof(DMeta) * 2))) return rc;
@@ -737,7 +809,8 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (double *)c->b_ew.p;
     b.ewl = (const uint64_t *)c->b_ewl.p;
     b.dist = (uint64_t *)c->b_dist.p; b.parent = (int32_t *)c->b_parent.p;
-    phxk_sssp(&b, n_limbs, s);
+    b.dist_stride = n_limbs;
+    hipLaunchSsspOnly(&b, n_limbs, s);
     HIPCHK(c, hipGetLastError());
     std::vector<int32_t> parent((size_t)V);
     std::vector<uint64_t> dist((size_t)V * (size_t)n_limbs);
@@ -749,7 +822,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     const uint64_t *dt = &dist[(size_t)(V - 1) * (size_t)n_limbs];
     if (dt[n_limbs - 1] == 0x7fffffffffffffffull) return PHX_OK; // unreachable: *n_path = 0
     std::vector<int32_t> rev;
-    for (int v = V - 1; v != V - 2 && (int)rev.size() <= V; v = parent[(size_t)v]) rev.push_back(v);
+    for (int v = V - 1; v != V - 2 && (int)rev.size() <= V; v = (int)esrc[(size_t)(uint32_t)parent[(size_t)v]]) rev.push_back(v); // parent holds in-edge indices
     rev.push_back(V - 2);
     if ((int)rev.size() > cap && path_out) return PHX_E_ARG;
     *n_path = (int32_t)rev.size();

@@ -9,11 +9,12 @@
 //       npos i32, ninfo i32, nlink u32, nother i32, no f64, in_off u32 (+1), dist NL x u64, parent i32
 //   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32, ew f64
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/phx.h"
 
-#define PHX_TILE 2048       // positions per feature-kernel workgroup
+#define PHX_TILE 1536       // positions per feature-kernel workgroup = 8 bitmap words (64 codons) per frame
 #define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
@@ -67,7 +68,7 @@ struct DGrp {
     int32_t n;
     int32_t node; // device node id of the stop node
     int32_t frame;
-    int32_t pad;
+    int32_t evkey; // position of the discovery event (0-based) or L + k for the k-th end fragment: reference insertion order
 };
 
 struct DBridge {
@@ -95,7 +96,14 @@ struct DMeta { // one per contig
     int32_t n_path;
     int64_t gene_off;
     int32_t sweeps;
-    int32_t pad;
+    int32_t nw;            // bitmap words per (class, frame) = 8 * number of feature tiles
+    int64_t bits_off;      // offset (in 64-bit words) of this contig's 12 bitmaps
+    int64_t item_off;      // offset of this contig's 6*nw scan items
+    int32_t n_orf_main, n_grp_main; // ORFs / groups emitted by the main loop (the end fragments follow)
+    int32_t sssp_nl;   // 64-bit limbs this contig's path sums need (2, 4, 8 or 17)
+    int32_t sssp_iters;
+    int32_t pad2;
+    int32_t sssp_mode; // 0 = global-memory kernel, 1 = LDS kernel (<= 64 KB), 2 = LDS kernel (<= 160 KB)
 };
 
 struct DTile {
@@ -119,6 +127,8 @@ struct DBatch {
     uint8_t *cls, *gcc, *cnt, *cov;
     uint16_t *rbs;
     uint32_t *linkF, *linkR;
+    uint64_t *bits;     // per contig: [class FS,RS,FT,RT][frame 0..2][nw] codon bitmaps, bit k of frame f <-> position f+3k
+    uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
     // per ORF / group
     DOrf *orf;
     DGrp *grp;
@@ -127,6 +137,7 @@ struct DBatch {
     uint32_t *nlink, *in_off;
     double *no;
     uint64_t *dist;
+    int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
     uint32_t *esrc;
     double *ew;
@@ -150,8 +161,8 @@ void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_edges_fill(const DBatch *b, void *stream);
-void phxk_sssp(const DBatch *b, int n_limbs, void *stream);
-void phxk_path(const DBatch *b, int n_limbs, void *stream);
+size_t phxk_sssp_lds_bytes(int V, int n_limbs);
+void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 #ifdef __cplusplus
 }
 #endif

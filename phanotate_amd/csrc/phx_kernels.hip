@@ -121,6 +121,7 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     __shared__ uint8_t s_code[FW];
     __shared__ uint16_t s_pref[FW];
     __shared__ uint8_t s_W[FW];
+    __shared__ uint8_t s_cls[PHX_TILE];
     __shared__ uint32_t s_AF[FW], s_AR[FW];
     __shared__ uint32_t s_t6[4096], s_t5[1024], s_t4[256], s_t3[64];
     __shared__ uint32_t s_hist[28];
@@ -211,47 +212,70 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     const DParams *P = b.params;
     for (int j = tid; j < PHX_TILE; j += PHX_FEAT_THREADS) {
         const int p = p0 + j;
-        if (p >= L) break;
-        const int idx = PHX_HALO + j;
-        const uint32_t c0 = s_code[idx], c1 = s_code[idx + 1], c2 = s_code[idx + 2];
-        uint32_t cls = 0, atg = 0, gcc = 0, cnt = 0;
-        if (p <= L - 3) {
-            if (!((c0 | c1 | c2) & 4u)) {
-                uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
-                cls = P->cls_tab[ci];
-                atg = P->atg_tab[ci];
-            }
-            int w0 = s_W[idx], w1 = s_W[idx + 1], w2 = s_W[idx + 2];
-            uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
-            uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
-            gcc = f | (r << 4);
-        }
-        { // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7
-            const uint32_t cc[3] = {c0, c1, c2};
-            for (int k = 0; k < 3; k++)
-                if (!(cc[k] & 4u)) {
-                    uint32_t x = cc[k] & 3u; // a0 c1 t2 g3
-                    cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
+        uint32_t cls = 0;
+        if (p < L) {
+            const int idx = PHX_HALO + j;
+            const uint32_t c0 = s_code[idx], c1 = s_code[idx + 1], c2 = s_code[idx + 2];
+            uint32_t atg = 0, gcc = 0, cnt = 0;
+            if (p <= L - 3) {
+                if (!((c0 | c1 | c2) & 4u)) {
+                    uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
+                    cls = P->cls_tab[ci];
+                    atg = P->atg_tab[ci];
                 }
-        }
-        // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21])
-        uint32_t bf = 0, br = 0;
-        if (p >= 20) {
-            for (int o = 3; o <= 15; o++) {
-                uint32_t s = (s_AF[idx - o] >> (8 * off_class(o))) & 0xffu;
-                bf = s > bf ? s : bf;
+                int w0 = s_W[idx], w1 = s_W[idx + 1], w2 = s_W[idx + 2];
+                uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
+                uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
+                gcc = f | (r << 4);
             }
-            atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
+            { // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7
+                const uint32_t cc[3] = {c0, c1, c2};
+                for (int k = 0; k < 3; k++)
+                    if (!(cc[k] & 4u)) {
+                        uint32_t x = cc[k] & 3u; // a0 c1 t2 g3
+                        cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
+                    }
+            }
+            // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21])
+            uint32_t bf = 0, br = 0;
+            if (p >= 20) {
+                for (int o = 3; o <= 15; o++) {
+                    uint32_t sc = (s_AF[idx - o] >> (8 * off_class(o))) & 0xffu;
+                    bf = sc > bf ? sc : bf;
+                }
+                atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
+            }
+            for (int o = 3; o <= 15; o++) {
+                uint32_t sc = (s_AR[idx + o] >> (8 * off_class(o))) & 0xffu;
+                br = sc > br ? sc : br;
+            }
+            atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
+            b.cls[off + p] = (uint8_t)cls;
+            b.gcc[off + p] = (uint8_t)gcc;
+            b.cnt[off + p] = (uint8_t)cnt;
+            b.rbs[off + p] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
         }
-        for (int o = 3; o <= 15; o++) {
-            uint32_t s = (s_AR[idx + o] >> (8 * off_class(o))) & 0xffu;
-            br = s > br ? s : br;
+        s_cls[j] = (uint8_t)(p <= L - 3 ? cls : 0u);
+    }
+    __syncthreads();
+    // 5. start/stop codon bitmaps by wavefront ballot: lane <-> codon, one 64-bit word per (class, frame, 64 codons).
+    //    p0 is a multiple of 1536 = 3*512, so codon f+3k of this tile is bit (k & 63) of word p0/192 + k/64.
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        uint64_t *bits = b.bits + meta->bits_off;
+        const int nw = meta->nw;
+        const int wbase = p0 / 192;
+        for (int pair = wv; pair < 24; pair += PHX_FEAT_THREADS / 64) {
+            const int f = pair >> 3, wi = pair & 7;
+            const uint32_t c = s_cls[f + 3 * (64 * wi + lane)] & 7u;
+            const uint64_t m1 = __ballot(c == CLS_FS), m2 = __ballot(c == CLS_RS), m3 = __ballot(c == CLS_FT), m4 = __ballot(c == CLS_RT);
+            if (lane == 0) {
+                bits[(size_t)(0 * 3 + f) * nw + wbase + wi] = m1;
+                bits[(size_t)(1 * 3 + f) * nw + wbase + wi] = m2;
+                bits[(size_t)(2 * 3 + f) * nw + wbase + wi] = m3;
+                bits[(size_t)(3 * 3 + f) * nw + wbase + wi] = m4;
+            }
         }
-        atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
-        b.cls[off + p] = (uint8_t)cls;
-        b.gcc[off + p] = (uint8_t)gcc;
-        b.cnt[off + p] = (uint8_t)cnt;
-        b.rbs[off + p] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
     }
     // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
     // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
@@ -289,84 +313,132 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
 }
 
 // ------------------------------------------------------------------------------------------------
-// ORF scan.  One workgroup per contig walks the positions in order; a thread that sits on a stop
-// event (forward stop codon, or the closing reverse-complement stop codon) owns that stop-group.
+// ORF scan on the codon bitmaps.  A "stop event" (forward stop codon, or the closing reverse-complement stop
+// codon) owns its stop-group (orfs.py:17-32).  Work item = one 64-codon word of one (strand, frame):
+// k_orf<false> counts ORFs / groups per item and turns the counts into exclusive offsets with one block
+// scan; k_orf<true> re-walks the items and writes the records.  The device order of groups is therefore
+// (strand, frame, codon); the reference's insertion order is kept as DGrp.evkey.
 struct OrfOut {
     DOrf *orf;
     DGrp *grp;
     uint32_t *linkF, *linkR;
 };
+struct FrameBits {
+    const uint64_t *FS, *RS, *FT, *RT;
+    int f;    // 0-based frame = position of codon 0
+    int ncod; // complete codons in this frame
+};
+// highest set bit with index < k, or -1
+__device__ __forceinline__ int prev_bit(const uint64_t *__restrict__ B, int k) {
+    if (k <= 0) return -1;
+    int w = (k - 1) >> 6;
+    uint64_t m = B[w] & (~0ull >> (63 - ((k - 1) & 63)));
+    while (true) {
+        if (m) return (w << 6) + 63 - __clzll((long long)m);
+        if (--w < 0) return -1;
+        m = B[w];
+    }
+}
+__device__ __forceinline__ uint64_t range_mask(int w, int lo, int hi) { // bits of word w that lie in [lo, hi]
+    uint64_t m = ~0ull;
+    if ((lo >> 6) == w) m &= ~0ull << (lo & 63);
+    if ((hi >> 6) == w) m &= ~0ull >> (63 - (hi & 63));
+    return m;
+}
 
-// Forward group closed by the stop codon (or, for the end fragment, the last codon of the frame) at 0-based p:
-// functions.py:202-214 / 229-239.  Starts are visited nearest first == reversed(starts[frame]).
+// Forward group closed by the stop codon (or, for the end fragment, the last codon of the frame) k:
+// functions.py:202-214 / 229-239.  Starts are emitted nearest first == reversed(starts[frame]).
 template <bool EMIT>
-__device__ int fwd_group(const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int p, int minlen, OrfOut o, int obase, int gidx) {
+__device__ int fwd_group(const FrameBits &F, const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int k, int dmin,
+                         OrfOut o, int obase, int gidx, int evkey) {
+    const int kp = prev_bit(F.FT, k);
+    const int lo = kp + 1, hi = k - dmin; // start codons ks with stop+2-start+1 >= minlen
+    const int p = F.f + 3 * k;
     int n = 0;
-    int q;
-    for (q = p - 3; q >= 0; q -= 3) {
-        const uint32_t cb = cls[q];
-        const int c = cb & 7;
-        if (c == CLS_FT) break;
-        if (c == CLS_FS && p - q + 3 >= minlen) {
-            if (EMIT) {
-                DOrf *r = &o.orf[obase + n];
-                r->start = q + 1; r->stop = p + 1; r->frame = (int8_t)(p % 3 + 1);
-                r->rbs = (uint8_t)(q >= 20 ? (rbs[q] & 31u) : 0u); // dna[start-21:start] is empty for start < 21 (functions.py:208)
-                r->startidx = (int8_t)((cb >> 3) & 15);
-                r->flags = (uint8_t)((rbs[q] >> 10) & 1u);
-                r->grp = gidx; r->node = -1;
-                o.linkF[q] = LINK_START | (uint32_t)(obase + n);
-            }
-            n++;
+    if (hi >= lo) {
+        for (int w = hi >> 6; w >= (lo >> 6); w--) {
+            uint64_t m = F.FS[w] & range_mask(w, lo, hi);
+            if (!EMIT) n += __popcll(m);
+            else
+                while (m) {
+                    const int j = 63 - __clzll((long long)m);
+                    m &= ~(1ull << j);
+                    const int q = F.f + 3 * ((w << 6) + j);
+                    DOrf *r = &o.orf[obase + n];
+                    r->start = q + 1; r->stop = p + 1; r->frame = (int8_t)(F.f + 1);
+                    r->rbs = (uint8_t)(q >= 20 ? (rbs[q] & 31u) : 0u); // dna[start-21:start] is empty for start < 21 (functions.py:208)
+                    r->startidx = (int8_t)((cls[q] >> 3) & 15);
+                    r->flags = (uint8_t)((rbs[q] >> 10) & 1u);
+                    r->grp = gidx; r->node = -1;
+                    o.linkF[q] = LINK_START | (uint32_t)(obase + n);
+                    n++;
+                }
         }
     }
-    if (q < 0) { // no stop to the left: the frame opens with a pseudo-start unless its first codon is a start (functions.py:186-191)
-        const int q0 = p % 3;
-        if ((cls[q0] & 7) != CLS_FS && q0 < p && p - q0 + 3 >= minlen) {
-            if (EMIT) {
-                DOrf *r = &o.orf[obase + n];
-                r->start = q0 + 1; r->stop = p + 1; r->frame = (int8_t)(p % 3 + 1);
-                r->rbs = 0; // start <= 3 < 21
-                r->startidx = -1;
-                r->flags = (uint8_t)((rbs[q0] >> 10) & 1u);
-                r->grp = gidx; r->node = -1;
-                o.linkF[q0] = LINK_START | (uint32_t)(obase + n);
-            }
-            n++;
+    // no stop to the left: the frame opens with a pseudo-start unless its first codon is a start (functions.py:186-191)
+    if (kp < 0 && !(F.FS[0] & 1ull) && hi >= 0 && k > 0) {
+        if (EMIT) {
+            const int q0 = F.f;
+            DOrf *r = &o.orf[obase + n];
+            r->start = q0 + 1; r->stop = p + 1; r->frame = (int8_t)(F.f + 1);
+            r->rbs = 0; // start <= 3 < 21
+            r->startidx = -1;
+            r->flags = (uint8_t)((rbs[q0] >> 10) & 1u);
+            r->grp = gidx; r->node = -1;
+            o.linkF[q0] = LINK_START | (uint32_t)(obase + n);
         }
+        n++;
     }
     if (EMIT && n) {
         DGrp *g = &o.grp[gidx];
-        g->stop = p + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = p % 3 + 1; g->pad = 0;
+        g->stop = p + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = F.f + 1; g->evkey = evkey;
         o.linkF[p] = LINK_STOP | (uint32_t)gidx;
     }
     return n;
 }
 
-// Reverse group: ORFs between the previous rc-stop of the frame and the pending rc-starts, emitted when
-// the closing rc-stop at p is met (functions.py:215-227), or after the loop for the open group
-// (functions.py:240-251; then `virt` is set, qe = last complete codon of the frame, and a pseudo-start
-// sits on qe unless rev_comp(codon) is a start codon).  Starts ascend == order of starts[-frame].
+// Reverse group: ORFs between the previous rc-stop of the frame (or the frame's first codon: stops =
+// {-1:1,-2:2,-3:3}, functions.py:184) and the pending rc-starts, emitted when the closing rc-stop k is
+// met (functions.py:215-227), or after the loop for the open group (virt: functions.py:240-251, with a
+// pseudo-start on the last codon unless rev_comp(codon) is a start codon).  Starts ascend.
 template <bool EMIT>
-__device__ int rev_group(const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int p, bool virt, int L, int minlen, OrfOut o, int obase, int gidx) {
-    // previous stop of this frame: a real RT codon, or the frame's first position (stops = {-1:1,-2:2,-3:3}, functions.py:184)
-    int q = virt ? p : p - 3;
-    for (; q >= 0; q -= 3)
-        if ((cls[q] & 7) == CLS_RT) break;
-    const int sk = q >= 0 ? q : p % 3; // 0-based stop key
-    const int shi = virt ? p : p - 3;
+__device__ int rev_group(const FrameBits &F, const uint8_t *__restrict__ cls, const uint16_t *__restrict__ rbs, int k, bool virt, int L,
+                         int dmin, OrfOut o, int obase, int gidx, int evkey) {
+    const int kp = prev_bit(F.RT, virt ? F.ncod : k);
+    const int sk = kp >= 0 ? kp : 0;
+    const int lo = sk + dmin, hi = virt ? F.ncod - 1 : k - 1;
+    const int psk = F.f + 3 * sk;
     int n = 0;
-    for (int s = sk + 3; s <= shi; s += 3) {
-        const uint32_t cb = cls[s];
-        bool real = (cb & 7) == CLS_RS;
-        bool pseudo = virt && s == p && !(cb & 0x80u);
-        if ((real || pseudo) && s - sk + 3 >= minlen) {
+    if (hi >= lo) {
+        for (int w = lo >> 6; w <= (hi >> 6); w++) {
+            uint64_t m = F.RS[w] & range_mask(w, lo, hi);
+            if (!EMIT) n += __popcll(m);
+            else
+                while (m) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int s = F.f + 3 * ((w << 6) + j);
+                    DOrf *r = &o.orf[obase + n];
+                    r->start = s + 1; r->stop = psk + 1; r->frame = (int8_t)(-(F.f + 1));
+                    const int jj = s + 3; // dna[start:start+21] with start = i+2 (functions.py:221)
+                    r->rbs = (uint8_t)(jj < L ? ((rbs[jj] >> 5) & 31u) : 0u);
+                    r->startidx = (int8_t)((cls[s] >> 3) & 15);
+                    r->flags = (uint8_t)((rbs[s] >> 11) & 1u);
+                    r->grp = gidx; r->node = -1;
+                    o.linkR[s] = LINK_START | (uint32_t)(obase + n);
+                    n++;
+                }
+        }
+    }
+    if (virt && F.ncod - 1 >= lo) {
+        const int s = F.f + 3 * (F.ncod - 1);
+        if (!(cls[s] & 0x80u)) { // functions.py:241-242
             if (EMIT) {
                 DOrf *r = &o.orf[obase + n];
-                r->start = s + 1; r->stop = sk + 1; r->frame = (int8_t)(-(p % 3 + 1));
-                const int j = s + 3; // dna[start:start+21] with start = i+2 (functions.py:221)
-                r->rbs = (uint8_t)(j < L ? ((rbs[j] >> 5) & 31u) : 0u);
-                r->startidx = (int8_t)(real ? ((cb >> 3) & 15) : -1);
+                r->start = s + 1; r->stop = psk + 1; r->frame = (int8_t)(-(F.f + 1));
+                const int jj = s + 3;
+                r->rbs = (uint8_t)(jj < L ? ((rbs[jj] >> 5) & 31u) : 0u);
+                r->startidx = -1;
                 r->flags = (uint8_t)((rbs[s] >> 11) & 1u);
                 r->grp = gidx; r->node = -1;
                 o.linkR[s] = LINK_START | (uint32_t)(obase + n);
@@ -376,10 +448,19 @@ __device__ int rev_group(const uint8_t *__restrict__ cls, const uint16_t *__rest
     }
     if (EMIT && n) {
         DGrp *g = &o.grp[gidx];
-        g->stop = sk + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = -(p % 3 + 1); g->pad = 0;
-        o.linkR[sk] = LINK_STOP | (uint32_t)gidx;
+        g->stop = psk + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = -(F.f + 1); g->evkey = evkey;
+        o.linkR[psk] = LINK_STOP | (uint32_t)gidx;
     }
     return n;
+}
+
+__device__ __forceinline__ FrameBits frame_bits(const uint64_t *bits, int nw, int f, int L) {
+    FrameBits F;
+    F.FS = bits + (size_t)(0 * 3 + f) * nw; F.RS = bits + (size_t)(1 * 3 + f) * nw;
+    F.FT = bits + (size_t)(2 * 3 + f) * nw; F.RT = bits + (size_t)(3 * 3 + f) * nw;
+    F.f = f;
+    F.ncod = L - f >= 3 ? (L - f) / 3 : 0;
+    return F;
 }
 
 template <bool EMIT>
@@ -397,42 +478,67 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
     const int64_t off = meta->off;
     const uint8_t *__restrict__ cls = b.cls + off;
     const uint16_t *__restrict__ rbs = b.rbs + off;
+    const uint64_t *bits = b.bits + meta->bits_off;
+    const int nw = meta->nw;
+    uint2 *item = b.item + meta->item_off;
     const int minlen = b.params->minlen;
+    const int dmin = (minlen - 1) / 3; // codons between start and stop so that the ORF length reaches minlen
     OrfOut o;
     o.orf = EMIT ? b.orf + meta->orf_off : nullptr;
     o.grp = EMIT ? b.grp + meta->grp_off : nullptr;
     o.linkF = b.linkF + off;
     o.linkR = b.linkR + off;
-    int run_orf = 0, run_grp = 0;
-    // main loop, functions.py:195: codon starts i = 1..L-2  <=>  p = 0..L-3
-    for (int base = 0; base < L - 2; base += NT) {
-        const int p = base + (int)threadIdx.x;
-        int n = 0, c = 0;
-        if (p <= L - 3) {
-            c = cls[p] & 7;
-            if (c == CLS_FT) n = fwd_group<false>(cls, rbs, p, minlen, o, 0, 0);
-            else if (c == CLS_RT) n = rev_group<false>(cls, rbs, p, false, L, minlen, o, 0, 0);
+    const int nitems = 6 * nw;
+    const int per = (nitems + NT - 1) / NT;
+    const int ia = (int)threadIdx.x * per, ib = ia + per < nitems ? ia + per : nitems;
+    uint32_t so = 0, sg = 0;
+    for (int it = ia; it < ib; it++) {
+        const int sf = it / nw, w = it - sf * nw;
+        const int s = sf / 3, f = sf - 3 * s;
+        const FrameBits F = frame_bits(bits, nw, f, L);
+        uint64_t m = (s == 0 ? F.FT : F.RT)[w];
+        uint32_t no = 0, ng = 0;
+        uint2 base = make_uint2(0, 0);
+        if (EMIT) base = item[it];
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int k = (w << 6) + j;
+            const int ev = f + 3 * k; // main-loop events are discovered in position order (functions.py:195)
+            const int n = s == 0 ? fwd_group<EMIT>(F, cls, rbs, k, dmin, o, (int)(base.x + no), (int)(base.y + ng), ev)
+                                 : rev_group<EMIT>(F, cls, rbs, k, false, L, dmin, o, (int)(base.x + no), (int)(base.y + ng), ev);
+            no += (uint32_t)n;
+            ng += n ? 1u : 0u;
         }
+        if (!EMIT) item[it] = make_uint2(no, ng);
+        so += no; sg += ng;
+    }
+    int run_orf, run_grp;
+    if (!EMIT) {
         uint32_t tot, gtot;
-        uint32_t ex = block_excl_scan<NT>((uint32_t)n, s_scan, &tot);
-        uint32_t gex = block_excl_scan<NT>(n ? 1u : 0u, s_scan, &gtot);
-        if (EMIT && n) {
-            if (c == CLS_FT) fwd_group<true>(cls, rbs, p, minlen, o, run_orf + (int)ex, run_grp + (int)gex);
-            else rev_group<true>(cls, rbs, p, false, L, minlen, o, run_orf + (int)ex, run_grp + (int)gex);
+        uint32_t exo = block_excl_scan<NT>(so, s_scan, &tot);
+        uint32_t exg = block_excl_scan<NT>(sg, s_scan, &gtot);
+        for (int it = ia; it < ib; it++) {
+            const uint2 c = item[it];
+            item[it] = make_uint2(exo, exg);
+            exo += c.x; exg += c.y;
         }
-        run_orf += (int)tot;
-        run_grp += (int)gtot;
+        run_orf = (int)tot; run_grp = (int)gtot;
+    } else {
+        run_orf = meta->n_orf_main; run_grp = meta->n_grp_main;
     }
     // fragments at the right end, functions.py:229-251: frame 1 fwd, frame 1 rev, frame 2 fwd, ...
     if (threadIdx.x == 0) {
+        if (!EMIT) { meta->n_orf_main = run_orf; meta->n_grp_main = run_grp; }
         for (int f = 0; f < 3; f++) {
-            if (L - f < 3) continue;
-            const int qe = f + 3 * ((L - f) / 3 - 1); // last complete codon of the frame
-            if ((cls[qe] & 7) != CLS_FT) { // else the main loop closed the group and starts[frame] is empty
-                int n = EMIT ? fwd_group<true>(cls, rbs, qe, minlen, o, run_orf, run_grp) : fwd_group<false>(cls, rbs, qe, minlen, o, 0, 0);
+            const FrameBits F = frame_bits(bits, nw, f, L);
+            if (F.ncod < 1) continue;
+            const int ke = F.ncod - 1;
+            if (!((F.FT[ke >> 6] >> (ke & 63)) & 1ull)) { // else the main loop closed the group and starts[frame] is empty
+                const int n = fwd_group<EMIT>(F, cls, rbs, ke, dmin, o, run_orf, run_grp, L + 2 * f);
                 run_orf += n; run_grp += n ? 1 : 0;
             }
-            int n = EMIT ? rev_group<true>(cls, rbs, qe, true, L, minlen, o, run_orf, run_grp) : rev_group<false>(cls, rbs, qe, true, L, minlen, o, 0, 0);
+            const int n = rev_group<EMIT>(F, cls, rbs, ke, true, L, dmin, o, run_orf, run_grp, L + 2 * f + 1);
             run_orf += n; run_grp += n ? 1 : 0;
         }
         if (!EMIT) { meta->n_orf = run_orf; meta->n_grp = run_grp; }
@@ -441,8 +547,15 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// ORF statistics: GC-frame class histogram and p_stop of every ORF (thread per ORF), then the GC frame
-// plot training of functions.py:261-279 (thread per stop-group).
+// ORF statistics, one wavefront per ORF (lanes stride the codons, 64-bit packed counters, butterfly reduce):
+// GC-frame class histogram (functions.py:286-298) and p_stop (orfs.py:162-173); then one wavefront per
+// stop-group for the GC frame plot training of functions.py:261-279.
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((long long)v, d);
+    return v;
+}
+
 __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
@@ -451,76 +564,85 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
     const uint8_t *__restrict__ cnt = b.cnt + off;
     DOrf *orf = b.orf + meta->orf_off;
     const DGrp *grp = b.grp + meta->grp_off;
-    for (int k = threadIdx.x; k < meta->n_orf; k += NT) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool ovf = false;
+    const int wglob = (int)blockIdx.y * (NT / 64) + wv, wstride = (int)gridDim.y * (NT / 64);
+    for (int k = wglob; k < meta->n_orf; k += wstride) {
         DOrf *r = &orf[k];
         const int start = r->start, stop = r->stop;
+        const bool fwd = r->frame > 0;
+        // codons of seq: fwd start..stop (the last one is the stop / last codon, not a sense codon, functions.py:207,290);
+        // rev start, start-3, .., stop (functions.py:220,295)
+        const int ncod = (fwd ? stop - start : start - stop) / 3 + 1;
+        if (ncod > 65535) ovf = true;
         uint64_t h0 = 0, h1 = 0, h2 = 0; // classes 0-2, 3-5, 6-8 in 21-bit fields
-        uint32_t na = 0, nt = 0, ng = 0, nc = 0;
-        if (r->frame > 0) {
-            // sense codons start..stop-3 (functions.py:290); seq also holds the stop / last codon (functions.py:207)
-            for (int base = start; base <= stop; base += 3) {
-                const uint32_t cb = cnt[base - 1];
-                na += cb & 3u; nt += (cb >> 2) & 3u; ng += (cb >> 4) & 3u; nc += (cb >> 6) & 3u;
-                if (base < stop) {
-                    const uint32_t c = gcc[base - 1] & 15u;
-                    const uint64_t inc = 1ull << (21 * (c % 3));
-                    h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
-                }
+        uint64_t at = 0, gc_ = 0;        // a | t<<32 ; g | c<<32
+        for (int i = lane; i < ncod; i += 64) {
+            const int base = fwd ? start + 3 * i : start - 3 * i;
+            const uint32_t cb = cnt[base - 1];
+            at += (uint64_t)(cb & 3u) | ((uint64_t)((cb >> 2) & 3u) << 32);
+            gc_ += (uint64_t)((cb >> 4) & 3u) | ((uint64_t)((cb >> 6) & 3u) << 32);
+            if (i < ncod - 1) {
+                const uint32_t g = gcc[base - 1];
+                const uint32_t c = fwd ? (g & 15u) : ((g >> 4) & 15u);
+                const uint64_t inc = 1ull << (21 * (c % 3));
+                h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
             }
-        } else {
-            // reverse: codons start, start-3, .., stop+3 (functions.py:295); seq = rev_comp(dna[stop-1:start+2])
-            for (int base = start; base >= stop; base -= 3) {
-                const uint32_t cb = cnt[base - 1];
-                na += cb & 3u; nt += (cb >> 2) & 3u; ng += (cb >> 4) & 3u; nc += (cb >> 6) & 3u;
-                if (base > stop) {
-                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
-                    const uint64_t inc = 1ull << (21 * (c % 3));
-                    h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
-                }
+        }
+        h0 = wave_sum_u64(h0); h1 = wave_sum_u64(h1); h2 = wave_sum_u64(h2);
+        at = wave_sum_u64(at); gc_ = wave_sum_u64(gc_);
+        if (lane == 0) {
+            for (int i = 0; i < 3; i++) {
+                r->hist[i] = (uint16_t)((h0 >> (21 * i)) & 0x1fffff);
+                r->hist[3 + i] = (uint16_t)((h1 >> (21 * i)) & 0x1fffff);
+                r->hist[6 + i] = (uint16_t)((h2 >> (21 * i)) & 0x1fffff);
             }
-            uint32_t t = na; na = nt; nt = t; // coding strand: a<->t, g<->c
-            ng = nc;
+            uint32_t na = (uint32_t)at, nt = (uint32_t)(at >> 32), ng = (uint32_t)gc_, nc = (uint32_t)(gc_ >> 32);
+            if (!fwd) { uint32_t t = na; na = nt; nt = t; ng = nc; } // coding strand: a<->t, g<->c
+            // Orf.p_stop, orfs.py:162-173
+            const double n = (double)(3 * ncod);
+            const double Pa = (double)na / n, Pt = (double)nt / n, Pg = (double)ng / n;
+            r->pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
+            atomicAdd(&meta->tr[r->rbs], 1u); // training_rbs, functions.py:211,224,239,251
         }
-        for (int i = 0; i < 3; i++) {
-            r->hist[i] = (uint16_t)((h0 >> (21 * i)) & 0x1fffff);
-            r->hist[3 + i] = (uint16_t)((h1 >> (21 * i)) & 0x1fffff);
-            r->hist[6 + i] = (uint16_t)((h2 >> (21 * i)) & 0x1fffff);
-        }
-        // Orf.p_stop, orfs.py:162-173
-        const int len = r->frame > 0 ? stop + 2 - start + 1 : start + 2 - stop + 1;
-        const double n = (double)len;
-        const double Pa = (double)na / n, Pt = (double)nt / n, Pg = (double)ng / n;
-        r->pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
-        atomicAdd(&meta->tr[r->rbs], 1u); // training_rbs, functions.py:211,224,239,251
     }
     // GC frame plot training: per group, the first ORF longest->shortest whose start codon is 'atg'
-    for (int g = threadIdx.x; g < meta->n_grp; g += NT) {
+    for (int g = wglob; g < meta->n_grp; g += wstride) {
         const DGrp G = grp[g];
-        for (int k = G.n - 1; k >= 0; k--) { // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46)
-            const DOrf *r = &orf[G.orf_begin + k];
-            if (!(r->flags & 1)) continue;
-            const int start = r->start, stop = r->stop;
-            uint32_t mx[4] = {0, 0, 0, 0}, mn[4] = {0, 0, 0, 0};
-            if (start < stop) {
-                const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
-                for (int base = start + nn; base < stop - 36; base += 3) {
-                    const uint32_t c = gcc[base - 1] & 15u;
-                    mx[c / 3 + 1]++; mn[c % 3 + 1]++;
-                }
-            } else if (stop < start) {
-                const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
-                for (int base = start - nn; base > stop + 36; base -= 3) {
-                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
-                    mx[c / 3 + 1]++; mn[c % 3 + 1]++;
-                }
-            }
-            for (int i = 1; i < 4; i++) {
-                if (mx[i]) atomicAdd(&meta->pmax[i], mx[i]);
-                if (mn[i]) atomicAdd(&meta->pmin[i], mn[i]);
-            }
-            break; // functions.py:279
+        // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46): search from the back
+        int pick = -1;
+        for (int k0 = G.n - 1; k0 >= 0 && pick < 0; k0 -= 64) {
+            const int k = k0 - lane;
+            const bool atg = k >= 0 && (orf[G.orf_begin + k].flags & 1);
+            const uint64_t m = __ballot(atg);
+            if (m) pick = k0 - (__ffsll((long long)m) - 1);
         }
+        if (pick < 0) continue;
+        const DOrf *r = &orf[G.orf_begin + pick];
+        const int start = r->start, stop = r->stop;
+        uint64_t mx = 0, mn = 0; // three 16-bit fields each (index 1..3)
+        if (start < stop) {
+            const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
+            for (int base = start + nn + 3 * lane; base < stop - 36; base += 192) {
+                const uint32_t c = gcc[base - 1] & 15u;
+                mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
+            }
+        } else if (stop < start) {
+            const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
+            for (int base = start - nn - 3 * lane; base > stop + 36; base -= 192) {
+                const uint32_t c = (gcc[base - 1] >> 4) & 15u;
+                mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
+            }
+        }
+        mx = wave_sum_u64(mx); mn = wave_sum_u64(mn);
+        if (lane == 0)
+            for (int i = 0; i < 3; i++) {
+                const uint32_t a = (uint32_t)((mx >> (16 * i)) & 0xffff), c = (uint32_t)((mn >> (16 * i)) & 0xffff);
+                if (a) atomicAdd(&meta->pmax[i + 1], a);
+                if (c) atomicAdd(&meta->pmin[i + 1], c);
+            }
     }
+    if (ovf) atomicMin(&meta->status, PHX_S_OVERFLOW);
 }
 
 // ORF weight: functions.py:254-257 (RBS), 281-284 (normalise), 286-301 + orfs.py:122-127.
@@ -572,12 +694,15 @@ __global__ __launch_bounds__(NT) void k_score(DBatch b) {
 // ------------------------------------------------------------------------------------------------
 // Nodes: one per ORF start and one per stop-group, sorted by position (then forward before reverse).
 // Also the coverage scan that finds the >500 bp uncovered runs of functions.py:320-334.
-struct LinkInfo { int time; int val; bool stop; int idx; };
+struct LinkInfo { int time; int val; bool stop; int idx; int far; };
+// time = when the reference wrote other_end[pos] for this slot (all ORFs of one group are added by one
+// event, so the group's evkey orders the writers); val = what it wrote last; far = index of the group's
+// farthest ORF when the slot is a stop node.
 __device__ __forceinline__ LinkInfo link_info(uint32_t link, const DOrf *orf, const DGrp *grp) {
     LinkInfo r;
     r.idx = (int)LINK_IDX(link);
-    if (LINK_KIND(link) == LINK_START) { r.stop = false; r.time = r.idx; r.val = orf[r.idx].stop; }
-    else { r.stop = true; const DGrp g = grp[r.idx]; r.time = g.orf_begin + g.n - 1; r.val = orf[r.time].start; }
+    if (LINK_KIND(link) == LINK_START) { r.stop = false; r.far = -1; r.time = grp[orf[r.idx].grp].evkey; r.val = orf[r.idx].stop; }
+    else { r.stop = true; const DGrp g = grp[r.idx]; r.far = g.orf_begin + g.n - 1; r.time = g.evkey; r.val = orf[r.far].start; }
     return r;
 }
 
@@ -657,7 +782,7 @@ __global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
         int oe = a.val;
         double o = pgap;
         if (!lother) {
-            if (a.stop) o = orf[a.time].pstop; // longest ORF of the group
+            if (a.stop) o = orf[a.far].pstop; // longest ORF of the group
         } else {
             LinkInfo c = link_info(lother, orf, grp);
             const bool other_wins = c.time > a.time;
@@ -707,12 +832,8 @@ __device__ __forceinline__ void emit_edge(EdgeSink &s, int src, double w) {
 
 template <bool FILL>
 __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
-    __shared__ uint32_t s_scan[NT / 64 + 1];
     DMeta *meta = &b.meta[blockIdx.x];
-    if (meta->status < 0 || meta->n_node <= 0) {
-        if (!FILL && threadIdx.x == 0) meta->n_edge = 0;
-        return;
-    }
+    if (meta->status < 0 || meta->n_node <= 0) return;
     const int L = meta->L;
     const int V = meta->n_node, ncds = V - 2, SRC = V - 2, TGT = V - 1;
     const DOrf *orf = b.orf + meta->orf_off;
@@ -724,9 +845,8 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
     const double pgap = contig_pstop(meta->gc, L);
     const int nbr = meta->n_bridge;
     bool parallel = false;
-    uint32_t run_edges = 0;
 
-    for (int base = 0; base < V; base += NT) {
+    for (int base = (int)blockIdx.y * NT; base < V; base += (int)gridDim.y * NT) {
         const int v = base + (int)threadIdx.x;
         EdgeSink sink;
         sink.n = 0;
@@ -818,15 +938,29 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                 }
             }
         }
-        if (!FILL) {
-            uint32_t tot;
-            uint32_t ex = block_excl_scan<NT>((uint32_t)sink.n, s_scan, &tot);
-            if (v < V) in_off[v] = run_edges + ex;
-            run_edges += tot; // block-uniform
-        }
+        if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
     }
-    if (!FILL && threadIdx.x == 0) { in_off[V] = run_edges; meta->n_edge = (int)run_edges; }
     if (parallel) atomicMin(&meta->status, PHX_S_PARALLEL);
+}
+
+// in-degrees -> exclusive offsets (CSR by destination), one workgroup per contig
+__global__ __launch_bounds__(NT) void k_edges_scan(DBatch b) {
+    __shared__ uint32_t s_scan[NT / 64 + 1];
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0 || meta->n_node <= 0) {
+        if (threadIdx.x == 0) meta->n_edge = 0;
+        return;
+    }
+    const int V = meta->n_node;
+    uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
+    const int per = (V + NT - 1) / NT;
+    const int a = (int)threadIdx.x * per, e = a + per < V ? a + per : V;
+    uint32_t sum = 0;
+    for (int v = a; v < e; v++) sum += in_off[v];
+    uint32_t tot;
+    uint32_t ex = block_excl_scan<NT>(sum, s_scan, &tot);
+    for (int v = a; v < e; v++) { const uint32_t d = in_off[v]; in_off[v] = ex; ex += d; }
+    if (threadIdx.x == 0) { in_off[V] = tot; meta->n_edge = (int)tot; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -919,112 +1053,32 @@ __device__ __forceinline__ void wi_store(uint64_t *p, const WInt<NL> &a) {
 }
 
 // Shortest path source -> target with exact integer weights trunc(w*1000) (edges.py:22; fastpathz keeps
-// the integer part).  The graph is not a DAG: nodes are relaxed in position order in chunks of
-// NT, each chunk iterated (Jacobi inside the chunk, so the result is schedule-independent) until stable,
-// and the sweep over chunks is repeated until a sweep changes nothing.  The fixed point of min-plus
-// relaxation is the unique exact distance vector; ties between equal-length paths are broken by the
-// in-edge order (first minimal in-edge wins), see DESIGN.md.
-template <int NL>
-__global__ __launch_bounds__(NT) void k_sssp(DBatch b) {
-    __shared__ int s_flag[2];
-    DMeta *meta = &b.meta[blockIdx.x];
-    const int V = meta->n_node;
-    if (meta->status < 0 || V <= 2) {
-        if (threadIdx.x == 0) meta->sweeps = 0;
-        return;
-    }
-    const int SRC = V - 2;
-    const uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
-    const uint32_t *esrc = b.esrc + meta->edge_off;
-    const double *ew = b.ew + meta->edge_off;
-    const uint64_t *ewl = b.ewl ? b.ewl + (size_t)meta->edge_off * NL : nullptr; // phx_solve: integer weights given as limbs
-    uint64_t *dist = b.dist + (size_t)meta->node_off * NL;
-    int32_t *parent = b.parent + meta->node_off;
-    const int tid = threadIdx.x;
-    for (int v = tid; v < V; v += NT) {
-        WInt<NL> d = wi_inf<NL>();
-        if (v == SRC) {
-#pragma unroll
-            for (int i = 0; i < NL; i++) d.v[i] = 0;
-        }
-        wi_store<NL>(dist + (size_t)v * NL, d);
-        parent[v] = -1;
-    }
-    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-    __syncthreads();
-    const int nchunk = (V + NT - 1) / NT;
-    int sweeps = 0, it = 0;
-    bool any = true, bad = false;
-    while (any && !bad) {
-        any = false;
-        for (int c = 0; c < nchunk; c++) {
-            const int v = c * NT + tid;
-            int inner = 0;
-            bool chg = true;
-            while (chg) {
-                bool improved = false;
-                WInt<NL> best;
-                int bp = -1;
-                if (v < V && v != SRC) {
-                    best = wi_load<NL>(dist + (size_t)v * NL);
-                    const uint32_t e0 = in_off[v], e1 = in_off[v + 1];
-                    for (uint32_t e = e0; e < e1; e++) {
-                        const uint32_t u = esrc[e];
-                        const WInt<NL> du = wi_load<NL>(dist + (size_t)u * NL);
-                        if (wi_is_inf<NL>(du)) continue;
-                        const WInt<NL> w = ewl ? wi_load<NL>(ewl + (size_t)e * NL) : wi_from_double<NL>(trunc(ew[e] * 1000.0));
-                        const WInt<NL> cand = wi_add<NL>(du, w);
-                        if (wi_lt<NL>(cand, best)) { best = cand; bp = (int)u; }
-                    }
-                    improved = bp >= 0;
-                }
-                __syncthreads(); // every read of this iteration is done
-                if (improved) {
-                    wi_store<NL>(dist + (size_t)v * NL, best);
-                    parent[v] = bp;
-                    s_flag[it & 1] = 1;
-                }
-                if (tid == 0) s_flag[(it + 1) & 1] = 0;
-                __syncthreads();
-                chg = s_flag[it & 1] != 0;
-                it++;
-                any = any || chg;
-                if (++inner > NT + 8) { bad = true; break; } // a chunk of NT nodes converges in <= NT rounds unless a cycle is negative
-            }
-            if (bad) break;
-        }
-        if (++sweeps > V + 2) bad = true;
-    }
-    if (tid == 0) {
-        meta->sweeps = sweeps;
-        if (bad) meta->status = PHX_S_NEGCYCLE;
-    }
-}
+// the integer part).  The graph is not a DAG: nodes are relaxed in position order, window by
+// window, each window iterated (Jacobi inside the window, so the result is schedule-independent) until it
+// is stable, and the sweep over windows is repeated until a whole sweep changes no distance.  The fixed
+// point of min-plus relaxation is the unique exact distance vector.  Ties between equal-length paths are
+// broken canonically: parent = the tight in-edge with the lowest in-edge index (every node re-evaluates
+// all its in-edges in the last, change-free sweep), see DESIGN.md.
+#define PE_NONE 0xffffffffu
 
-// Path -> genes (phanotate.py:65-76, locus.py:29-37).  One thread per contig.
-template <int NL>
-__global__ void k_path(DBatch b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= b.n_contig) return;
-    DMeta *meta = &b.meta[c];
+// path -> genes (phanotate.py:65-76, locus.py:29-37); pedge[v] = in-edge index (contig-relative) of v's parent
+__device__ void emit_path_and_genes(const DBatch &b, DMeta *meta, const uint32_t *pedge, bool target_reached) {
     meta->n_genes = 0; meta->n_path = 0; meta->gene_off = 0;
     const int V = meta->n_node;
-    if (meta->status < 0 || V <= 2) return; // phanotate.py:63: len(graph) > 2
     const int SRC = V - 2, TGT = V - 1;
-    const uint64_t *dist = b.dist + (size_t)meta->node_off * NL;
-    const int32_t *parent = b.parent + meta->node_off;
+    const uint32_t *esrc = b.esrc + meta->edge_off;
     const int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
     const uint32_t *nlink = b.nlink + meta->node_off;
     const DOrf *orf = b.orf + meta->orf_off;
     const DGrp *grp = b.grp + meta->grp_off;
     int32_t *path = b.path + meta->node_off;
-    if (dist[(size_t)TGT * NL + NL - 1] == WINF_TOP) { meta->status = PHX_S_NOPATH; return; }
+    if (!target_reached) { meta->status = PHX_S_NOPATH; return; }
     int n = 0;
-    for (int v = TGT; v != SRC && n <= V; v = parent[v]) n++;
+    for (int v = TGT; v != SRC && n <= V; v = (int)esrc[pedge[v]]) n++;
     if (n > V) { meta->status = PHX_S_NEGCYCLE; return; }
     {
         int k = n;
-        for (int v = TGT; k >= 0; v = parent[v]) { path[k--] = v; if (v == SRC) break; }
+        for (int v = TGT;; v = (int)esrc[pedge[v]]) { path[k--] = v; if (v == SRC || k < 0) break; }
     }
     meta->n_path = n + 1;
     const int npairs = n / 2; // shortest_path[1:] taken two at a time (file_handling.pairwise)
@@ -1052,6 +1106,357 @@ __global__ void k_path(DBatch b) {
     }
 }
 
+// ---- general kernel: distances in global memory (any V); also serves phx_solve ----
+template <int NL>
+__global__ __launch_bounds__(NT) void k_sssp(DBatch b) {
+    __shared__ int s_flag[2];
+    DMeta *meta = &b.meta[blockIdx.x];
+    const int V = meta->n_node;
+    if (meta->status < 0 || V <= 2 || meta->sssp_nl != NL || meta->sssp_mode != 0) return;
+    const int SRC = V - 2;
+    const uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
+    const uint32_t *esrc = b.esrc + meta->edge_off;
+    const double *ew = b.ew + meta->edge_off;
+    const uint64_t *ewl = b.ewl ? b.ewl + (size_t)meta->edge_off * NL : nullptr; // phx_solve: integer weights given as limbs
+    uint64_t *dist = b.dist + (size_t)meta->node_off * b.dist_stride;
+    uint32_t *pedge = (uint32_t *)(b.parent + meta->node_off);
+    const int tid = threadIdx.x;
+    for (int v = tid; v < V; v += NT) {
+        WInt<NL> d = wi_inf<NL>();
+        if (v == SRC) {
+#pragma unroll
+            for (int i = 0; i < NL; i++) d.v[i] = 0;
+        }
+        wi_store<NL>(dist + (size_t)v * NL, d);
+        pedge[v] = PE_NONE;
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    __syncthreads();
+    const int nchunk = (V + NT - 1) / NT;
+    int sweeps = 0, it = 0;
+    bool any = true, bad = false;
+    while (any && !bad) {
+        any = false;
+        for (int c = 0; c < nchunk; c++) {
+            const int v = c * NT + tid;
+            int inner = 0;
+            bool chg = true;
+            while (chg) {
+                bool improved = false, moved = false;
+                WInt<NL> best;
+                uint32_t be = PE_NONE;
+                if (v < V && v != SRC) {
+                    best = wi_load<NL>(dist + (size_t)v * NL);
+                    be = pedge[v];
+                    const uint32_t be0 = be;
+                    const uint32_t e0 = in_off[v], e1 = in_off[v + 1];
+                    for (uint32_t e = e0; e < e1; e++) {
+                        const uint32_t u = esrc[e];
+                        const WInt<NL> du = wi_load<NL>(dist + (size_t)u * NL);
+                        if (wi_is_inf<NL>(du)) continue;
+                        const WInt<NL> w = ewl ? wi_load<NL>(ewl + (size_t)e * NL) : wi_from_double<NL>(trunc(ew[e] * 1000.0));
+                        const WInt<NL> cand = wi_add<NL>(du, w);
+                        if (wi_lt<NL>(cand, best)) { best = cand; be = e; improved = true; }
+                        else if (e < be && wi_eq<NL>(cand, best)) be = e;
+                    }
+                    moved = be != be0;
+                }
+                __syncthreads(); // every read of this iteration is done
+                if (improved || moved) {
+                    if (improved) { wi_store<NL>(dist + (size_t)v * NL, best); s_flag[it & 1] = 1; }
+                    pedge[v] = be;
+                }
+                if (tid == 0) s_flag[(it + 1) & 1] = 0;
+                __syncthreads();
+                chg = s_flag[it & 1] != 0;
+                it++;
+                any = any || chg;
+                if (++inner > NT + 8) { bad = true; break; } // a chunk of NT nodes converges in <= NT rounds unless a cycle is negative
+            }
+            if (bad) break;
+        }
+        if (++sweeps > V + 2) bad = true;
+    }
+    if (tid == 0) {
+        meta->sweeps = sweeps;
+        meta->sssp_iters = it;
+        if (bad) meta->status = PHX_S_NEGCYCLE;
+    }
+}
+
+template <int NL>
+__global__ void k_path(DBatch b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= b.n_contig) return;
+    DMeta *meta = &b.meta[c];
+    const int V = meta->n_node;
+    if (meta->sssp_nl != NL || meta->sssp_mode != 0) return;
+    meta->n_genes = 0; meta->n_path = 0; meta->gene_off = 0;
+    if (meta->status < 0 || V <= 2) return; // phanotate.py:63: len(graph) > 2
+    const uint64_t *dist = b.dist + (size_t)meta->node_off * b.dist_stride;
+    emit_path_and_genes(b, meta, (const uint32_t *)(b.parent + meta->node_off), dist[(size_t)(V - 1) * NL + NL - 1] != WINF_TOP);
+}
+
+// ---- fast kernel: distances and the current window's in-edges live in LDS ----
+// 1024 threads = 64 nodes x 16 lanes (one DPP row per node).  A window is 32 new nodes plus the nodes of
+// the next 500 bp (every connector edge that points backwards spans < 500 bp, functions.py:372), so that
+// after the window has converged its first 32 nodes are final in all but pathological cases; the outer
+// sweep loop keeps the result exact regardless.  The relaxation tracks distances only; parents are chosen
+// once at the end (lowest-index tight in-edge), which is also what makes ties schedule-independent.
+#define SW_ADV 32
+#define SW_MAX 64
+#define SW_ECAP 1536
+#ifndef SW_LPN
+#define SW_LPN 8 // lanes per node (4, 8 or 16; a DPP row has 16 lanes)
+#endif
+#define SW_THREADS (SW_MAX * SW_LPN)
+//#define SW_PROFILE 1
+
+// "infinity" that survives one addition of any edge weight without wrapping: 2^(64*NL-2).
+// Real distances stay below 2^(64*NL-3) in magnitude (the host picks NL that way).
+#define WBIG_TOP 0x4000000000000000ull
+template <int NL>
+__device__ __forceinline__ bool wi_unreached(const WInt<NL> &a) { return (int64_t)a.v[NL - 1] >= (int64_t)0x2000000000000000ull; }
+// branch-free signed a < b
+template <int NL>
+__device__ __forceinline__ bool wi_lt_bf(const WInt<NL> &a, const WInt<NL> &b) {
+    bool lt = a.v[0] < b.v[0];
+#pragma unroll
+    for (int i = 1; i < NL - 1; i++) lt = (a.v[i] < b.v[i]) | ((a.v[i] == b.v[i]) & lt);
+    if (NL > 1) lt = ((int64_t)a.v[NL - 1] < (int64_t)b.v[NL - 1]) | ((a.v[NL - 1] == b.v[NL - 1]) & lt);
+    return lt;
+}
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_min_bf(const WInt<NL> &a, const WInt<NL> &b) {
+    const bool lt = wi_lt_bf<NL>(b, a);
+    WInt<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = lt ? b.v[i] : a.v[i];
+    return r;
+}
+// value of the lane `n` places to the left inside the 16-lane DPP row (own value for the first n lanes)
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + N, 0xf, 0xf, false); }
+template <int N, int NL>
+__device__ __forceinline__ WInt<NL> wi_row_shr(const WInt<NL> &a) {
+    WInt<NL> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t lo = dpp_row_shr<N>((uint32_t)a.v[i]), hi = dpp_row_shr<N>((uint32_t)(a.v[i] >> 32));
+        r.v[i] = ((uint64_t)hi << 32) | lo;
+    }
+    return r;
+}
+// after this, the last lane of every SW_LPN-lane group holds the minimum of the group
+template <int NL>
+__device__ __forceinline__ WInt<NL> wi_row_min(WInt<NL> x, int sub) {
+    WInt<NL> y;
+    y = wi_min_bf<NL>(x, wi_row_shr<1, NL>(x)); if (sub >= 1) x = y;
+    y = wi_min_bf<NL>(x, wi_row_shr<2, NL>(x)); if (sub >= 2) x = y;
+    if (SW_LPN > 4) { y = wi_min_bf<NL>(x, wi_row_shr<4, NL>(x)); if (sub >= 4) x = y; }
+    if (SW_LPN > 8) { y = wi_min_bf<NL>(x, wi_row_shr<8, NL>(x)); if (sub >= 8) x = y; }
+    return x;
+}
+__device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
+    uint32_t o;
+    o = dpp_row_shr<1>(x); if (sub >= 1 && o < x) x = o;
+    o = dpp_row_shr<2>(x); if (sub >= 2 && o < x) x = o;
+    if (SW_LPN > 4) { o = dpp_row_shr<4>(x); if (sub >= 4 && o < x) x = o; }
+    if (SW_LPN > 8) { o = dpp_row_shr<8>(x); if (sub >= 8 && o < x) x = o; }
+    return x;
+}
+
+template <int NL>
+__global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_flag[2];
+    __shared__ int s_v1, s_np;
+    __shared__ uint32_t s_off[SW_MAX + 1];
+    DMeta *meta = &b.meta[blockIdx.x];
+    const int V = meta->n_node;
+    if (meta->status < 0 || V <= 2 || meta->sssp_nl != NL || meta->sssp_mode != mode) return;
+    const int tid = threadIdx.x;
+    const int SRC = V - 2, TGT = V - 1, ncds = V - 2;
+    const uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
+    const uint32_t *esrc = b.esrc + meta->edge_off;
+    const double *ew = b.ew + meta->edge_off;
+    const int32_t *npos = b.npos + meta->node_off;
+    // LDS carve: dist V*NL u64 | tile weights SW_ECAP*NL u64 | tile sources SW_ECAP u32
+    // (after convergence the tile area is reused for the parent node of every node)
+    uint64_t *dist = (uint64_t *)smem;
+    uint64_t *tw = dist + (size_t)V * NL;
+    uint32_t *tsrc = (uint32_t *)(tw + (size_t)SW_ECAP * NL);
+    uint32_t *psrc = (uint32_t *)tw;
+    for (int v = tid; v < V; v += SW_THREADS) {
+        WInt<NL> d;
+#pragma unroll
+        for (int i = 0; i < NL; i++) d.v[i] = 0;
+        if (v != SRC) d.v[NL - 1] = WBIG_TOP;
+        wi_store<NL>(dist + (size_t)v * NL, d);
+    }
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    __syncthreads();
+    const int node_l = tid / SW_LPN, sub = tid % SW_LPN;
+#ifdef SW_PROFILE
+    long long t_setup = 0, t_iter = 0, t_mark = wall_clock64();
+#endif
+    int sweeps = 0, it = 0;
+    bool any = true, bad = false;
+    while (any && !bad) {
+        any = false;
+        for (int v0 = 0; v0 < V && !bad;) {
+            // ---- window [v0, v1): SW_ADV nodes to advance by, plus look-ahead ----
+            const int vadv = v0 + SW_ADV < V ? v0 + SW_ADV : V;
+            if (tid < 64) {
+                const int idx = v0 + tid;
+                bool ok = idx < V;
+                if (ok && idx >= vadv) ok = idx < ncds && vadv - 1 < ncds && npos[idx] < npos[vadv - 1] + 500;
+                if (ok && idx > v0) ok = in_off[idx + 1] - in_off[v0] <= SW_ECAP; // the first node always fits (in-degree << SW_ECAP)
+                const uint64_t m = __ballot(ok);
+                const int cnt = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
+                if (tid == 0) s_v1 = v0 + (cnt < 1 ? 1 : cnt);
+            }
+            __syncthreads();
+            const int v1 = s_v1;
+            const int nwin = v1 - v0;
+            const int adv = vadv < v1 ? vadv : v1; // if the edge cap cut the window short, advance less
+            if (tid <= nwin) s_off[tid] = in_off[v0 + tid];
+            __syncthreads();
+            const uint32_t e0 = s_off[0];
+            const int ne = (int)(s_off[nwin] - e0);
+            const bool tiled = ne <= SW_ECAP; // false only if a single node has more in-edges than the tile holds
+            if (tiled)
+                for (int i = tid; i < ne; i += SW_THREADS) {
+                    tsrc[i] = esrc[e0 + i];
+                    wi_store<NL>(tw + (size_t)i * NL, wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0)));
+                }
+            __syncthreads();
+#ifdef SW_PROFILE
+            { long long t = wall_clock64(); t_setup += t - t_mark; t_mark = t; }
+#endif
+            // ---- iterate the window to its fixed point ----
+            const int v = v0 + node_l;
+            const bool act = node_l < nwin;
+            const int ia = act ? (int)(s_off[node_l] - e0) + sub : 0;
+            const int ib = act ? (int)(s_off[node_l + 1] - e0) : 0;
+            int inner = 0;
+            bool chg = true;
+            while (chg) {
+                WInt<NL> d0;
+#pragma unroll
+                for (int i = 0; i < NL; i++) d0.v[i] = 0;
+                d0.v[NL - 1] = WBIG_TOP;
+                if (act) d0 = wi_load<NL>(dist + (size_t)v * NL);
+                WInt<NL> best = d0;
+                if (tiled) {
+                    for (int i = ia; i < ib; i += SW_LPN) {
+                        const uint32_t u = tsrc[i];
+                        const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)u * NL), wi_load<NL>(tw + (size_t)i * NL));
+                        best = wi_min_bf<NL>(best, cand);
+                    }
+                } else {
+                    for (int i = ia; i < ib; i += SW_LPN) {
+                        const uint32_t u = esrc[e0 + i];
+                        const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)u * NL), wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0)));
+                        best = wi_min_bf<NL>(best, cand);
+                    }
+                }
+                best = wi_row_min<NL>(best, sub);
+                const bool improved = act && sub == SW_LPN - 1 && wi_lt_bf<NL>(best, d0);
+                __syncthreads(); // every read of this iteration is done
+                if (improved) { wi_store<NL>(dist + (size_t)v * NL, best); s_flag[it & 1] = 1; }
+                if (tid == 0) s_flag[(it + 1) & 1] = 0;
+                __syncthreads();
+                chg = s_flag[it & 1] != 0;
+                it++;
+                any = any || chg;
+                if (++inner > SW_MAX + 8) { bad = true; break; }
+            }
+#ifdef SW_PROFILE
+            { long long t = wall_clock64(); t_iter += t - t_mark; t_mark = t; }
+#endif
+            v0 = adv > v0 ? adv : v0 + 1;
+        }
+        if (++sweeps > V + 2) bad = true;
+    }
+    __syncthreads();
+    // ---- parents: the tight in-edge with the lowest index (canonical tie-break) ----
+    uint32_t *gpe = (uint32_t *)(b.parent + meta->node_off);
+    for (int vb = 0; vb < V; vb += SW_MAX) {
+        const int v = vb + node_l;
+        uint32_t be = PE_NONE;
+        if (v < V) {
+            const WInt<NL> dv = wi_load<NL>(dist + (size_t)v * NL);
+            if (!wi_unreached<NL>(dv)) {
+                const uint32_t e1 = in_off[v + 1];
+                for (uint32_t e = in_off[v] + sub; e < e1; e += SW_LPN) {
+                    const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)esrc[e] * NL), wi_from_double<NL>(trunc(ew[e] * 1000.0)));
+                    if (wi_eq<NL>(cand, dv) && e < be) be = e;
+                }
+            }
+        }
+        be = u32_row_min(be, sub);
+        if (v < V && sub == SW_LPN - 1) { gpe[v] = be; psrc[v] = be == PE_NONE ? PE_NONE : esrc[be]; }
+    }
+    if (tid < NL) (b.dist + (size_t)meta->node_off * b.dist_stride)[(size_t)TGT * NL + tid] = dist[(size_t)TGT * NL + tid];
+    __syncthreads();
+    // ---- path (phanotate.py:64-67) and genes (phanotate.py:71-76, locus.py:29-37) ----
+    int32_t *path = b.path + meta->node_off;
+    if (tid == 0) {
+        meta->sweeps = sweeps;
+        meta->sssp_iters = it;
+        meta->n_genes = 0; meta->n_path = 0; meta->gene_off = 0;
+        int np = -1;
+        if (bad) meta->status = PHX_S_NEGCYCLE;
+        else if (wi_unreached<NL>(wi_load<NL>(dist + (size_t)TGT * NL))) meta->status = PHX_S_NOPATH;
+        else {
+            int n = 0;
+            for (int v = TGT; v != SRC && n <= V; v = (int)psrc[v]) n++;
+            if (n > V) meta->status = PHX_S_NEGCYCLE;
+            else {
+                int k = n;
+                for (int v = TGT;; v = (int)psrc[v]) { path[k--] = v; if (v == SRC || k < 0) break; }
+                meta->n_path = n + 1;
+                np = n / 2; // shortest_path[1:] taken two at a time (file_handling.pairwise)
+                meta->n_genes = np;
+                meta->gene_off = atomicAdd(b.gene_total, (uint32_t)np);
+            }
+        }
+        s_np = np;
+#ifdef SW_PROFILE
+        { long long t = wall_clock64(); meta->pmax[0] = (uint32_t)t_setup; meta->pmin[0] = (uint32_t)t_iter; meta->pad2 = (int32_t)(t - t_mark); }
+#endif
+    }
+    __syncthreads();
+    const int npairs = s_np;
+    if (npairs > 0) {
+        const int32_t *ninfo = b.ninfo + meta->node_off;
+        const uint32_t *nlink = b.nlink + meta->node_off;
+        const DOrf *orf = b.orf + meta->orf_off;
+        const DGrp *grp = b.grp + meta->grp_off;
+        const int64_t g0 = meta->gene_off;
+        for (int i = tid; i < npairs; i += SW_THREADS) {
+            const int a = path[2 * i + 1], bb = path[2 * i + 2];
+            DGene g;
+            g.left = npos[a];
+            g.right = npos[bb] + 2; // locus.py:30
+            g.frame = NFRAME(ninfo[a]);
+            g.strand = g.frame < 0 ? -1 : 1;
+            double w = 0.0; // Graph.weight, graphs.py:91-96
+            const int ta = NTYPE(ninfo[a]);
+            if (ta == 0 && g.frame > 0 && LINK_KIND(nlink[a]) == LINK_START) {
+                const DOrf *r = &orf[LINK_IDX(nlink[a])];
+                if (grp[r->grp].node == bb) w = r->weight;
+            } else if (ta == 1 && g.frame < 0 && LINK_KIND(nlink[bb]) == LINK_START) {
+                const DOrf *r = &orf[LINK_IDX(nlink[bb])];
+                if (grp[r->grp].node == a) w = r->weight;
+            }
+            g.score = w;
+            b.genes[g0 + i] = g;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 extern "C" {
@@ -1060,13 +1465,17 @@ void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *strea
 }
 void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_train(const DBatch *, void *) {}
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_nodes(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_nodes, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_edges_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_sssp(const DBatch *b, int nl, void *stream) {
+void phxk_edges_count(const DBatch *b, void *stream) {
+    hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+}
+void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
+// phx_solve: the relaxation alone, no path/gene emission (the caller walks the parent edges)
+void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
     dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
     switch (nl) {
@@ -1076,14 +1485,40 @@ void phxk_sssp(const DBatch *b, int nl, void *stream) {
     default: hipLaunchKernelGGL(k_sssp<17>, g, t, 0, s, *b); break;
     }
 }
-void phxk_path(const DBatch *b, int nl, void *stream) {
-    dim3 g((b->n_contig + 63) / 64), t(64);
+
+size_t phxk_sssp_lds_bytes(int V, int nl) {
+    size_t tile = (size_t)SW_ECAP * ((size_t)nl * 8 + 4);
+    if (tile < (size_t)V * 4) tile = (size_t)V * 4; // the tile area later holds one parent per node
+    return (size_t)V * nl * 8 + tile + 64;
+}
+
+// mode 0: global-memory kernel (+ k_path); mode 1/2: LDS kernel with `lds_bytes` of dynamic LDS
+void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream) {
+    dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        dim3 gp((b->n_contig + 63) / 64), tp(64);
+        switch (nl) {
+        case 2: hipLaunchKernelGGL(k_sssp<2>, g, t, 0, s, *b); hipLaunchKernelGGL(k_path<2>, gp, tp, 0, s, *b); break;
+        case 4: hipLaunchKernelGGL(k_sssp<4>, g, t, 0, s, *b); hipLaunchKernelGGL(k_path<4>, gp, tp, 0, s, *b); break;
+        case 8: hipLaunchKernelGGL(k_sssp<8>, g, t, 0, s, *b); hipLaunchKernelGGL(k_path<8>, gp, tp, 0, s, *b); break;
+        default: hipLaunchKernelGGL(k_sssp<17>, g, t, 0, s, *b); hipLaunchKernelGGL(k_path<17>, gp, tp, 0, s, *b); break;
+        }
+        return;
+    }
     switch (nl) {
-    case 2: hipLaunchKernelGGL(k_path<2>, g, t, 0, s, *b); break;
-    case 4: hipLaunchKernelGGL(k_path<4>, g, t, 0, s, *b); break;
-    case 8: hipLaunchKernelGGL(k_path<8>, g, t, 0, s, *b); break;
-    default: hipLaunchKernelGGL(k_path<17>, g, t, 0, s, *b); break;
+    case 2:
+        (void)hipFuncSetAttribute((const void *)k_sssp_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k_sssp_lds<2>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+    case 4:
+        (void)hipFuncSetAttribute((const void *)k_sssp_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k_sssp_lds<4>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+    case 8:
+        (void)hipFuncSetAttribute((const void *)k_sssp_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k_sssp_lds<8>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+    default:
+        (void)hipFuncSetAttribute((const void *)k_sssp_lds<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(k_sssp_lds<17>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
     }
 }
 }

@@ -54,8 +54,8 @@ def report(case_filter=None):
             o = oracle.run(seq, op)
             st, genes = res[i]
             gl = ann.globals(i)
-            print("  %s: L=%d status gpu=%d oracle=%d  n_orf=%d n_node=%d n_edge=%d n_bridge=%d limbs=%d sweeps=%d" %
-                  (c, len(seq), st, o["status"], gl.n_orf, gl.n_node, gl.n_edge, gl.n_bridge, gl.n_limbs, gl.sssp_sweeps))
+            print("  %s: L=%d status gpu=%d oracle=%d  n_orf=%d n_node=%d n_edge=%d n_bridge=%d limbs=%d sweeps=%d iters=%d" %
+                  (c, len(seq), st, o["status"], gl.n_orf, gl.n_node, gl.n_edge, gl.n_bridge, gl.n_limbs, gl.sssp_sweeps, gl.sssp_iters))
             try:
                 ok = True
                 if o["status"] < 0:
