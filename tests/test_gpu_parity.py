@@ -2,6 +2,8 @@
 golden vectors.  Bar: bit-exact for every integer output (position bytes, ORF table, nodes, edge
 endpoints, path, gene coordinates, strands); fp64 edge weights / scores within 1e-9 of the oracle
 (same formulas, libm vs device math) and 1e-6 of the reference's Decimal values (north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -275,3 +277,84 @@ def test_solver_alone_exact_integers(pa, bits, nl):
             tot += min(cands)
         assert tot == dist
     ann.close()
+
+
+def test_cli_tabular_and_dump(pa, tmp_path):
+    """phanotate.py end to end: multi-contig FASTA in, the reference's tabular text out; and -d/--dump in the
+    reference's Graph.iteredges order (weights compared numerically: Decimal text cannot be reproduced in fp64)."""
+    import gzip
+    import re
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN, ROOT
+
+    cases = ["phiX174", "edge_L200", "synth6k_100", "edge_bridge"]
+    fa = tmp_path / "in.fasta"
+    want = ""
+    with open(fa, "w") as f:
+        for c in cases:
+            g, name, seq = load_golden(c)
+            f.write(">%s some description\n%s\n" % (name, seq))
+            want += str(g["tabular"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), str(fa)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want
+    for c in ("phiX174", "edge_bridge"):
+        g, name, seq = load_golden(c)
+        one = tmp_path / (c + ".fa")
+        one.write_text(">%s\n%s\n" % (name, seq))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), "-d", str(one)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().split("\n")
+        assert len(lines) == len(g["edge_src"])
+        tcode = {"start": 0, "stop": 1, "source": 2, "target": 3}
+        pat = re.compile(r"Node\('(\w+)','(\w+)',(-?\d+),(\d+)\)")
+        for k, line in enumerate(lines):
+            s, d, w = line.split("\t")
+            ms, md = pat.fullmatch(s), pat.fullmatch(d)
+            si, di = int(g["edge_src"][k]), int(g["edge_dst"][k])
+            assert (tcode[ms.group(2)], int(ms.group(3)), int(ms.group(4))) == (int(g["node_type"][si]), int(g["node_frame"][si]), int(g["node_pos"][si])), (c, k)
+            assert (tcode[md.group(2)], int(md.group(3)), int(md.group(4))) == (int(g["node_type"][di]), int(g["node_frame"][di]), int(g["node_pos"][di])), (c, k)
+            assert abs(float(w) / (float(g["edge_weight"][k]) * 1000) - 1) < 1e-9
+
+
+class _Locus:
+    def __init__(self, seq, start_codons=None, stop_codons=None, minlen=90):
+        self._seq = seq
+        self.start_codons = start_codons or {"atg": 1.0, "gtg": 0.10 / 0.85, "ttg": 0.05 / 0.85}
+        self.stop_codons = stop_codons or ["tag", "tga", "taa"]
+        self.min_orf_len = minlen
+
+    def seq(self):
+        return self._seq
+
+
+def test_reference_style_driver_loop(pa):
+    """The body of phanotate.py:40-76 written against the mirror modules (functions.get_orfs / get_graph and
+    the fastpathz shim): same call sequence, and the same genes as the golden vectors."""
+    from phanotate_amd import fastpathz as fz
+    from phanotate_amd import functions
+
+    for case in ("phiX174", "synth6k_101", "edge_L200"):
+        g, name, seq = load_golden(case)
+        locus = _Locus(seq)
+        orfs = functions.get_orfs(locus)
+        graph = functions.get_graph(orfs)
+        assert [o.start for o in orfs.iter_orfs()] == list(g["orf_start"])
+        assert [n.position for n in graph.iternodes()] == list(g["node_pos"])
+        fz.empty_graph()
+        for e in graph.iteredges():
+            fz.add_edge(str(e))
+        source = "Node('source','source',0,0)"
+        target = "Node('target','target',0," + str(len(seq) + 1) + ")"
+        shortest_path = fz.get_path(source=source, target=target)[1:] if len(graph) > 2 else []
+        got = []
+        it = iter(shortest_path)
+        for s, t in zip(it, it):
+            left, right = eval(s, {"Node": functions.Node}), eval(t, {"Node": functions.Node})
+            got.append((left.position, right.position + 2, graph.weight(functions.Edge(left, right, 0))))
+        assert [x[0] for x in got] == list(g["gene_left"]) and [x[1] for x in got] == list(g["gene_right"])
+        np.testing.assert_allclose([x[2] for x in got], g["gene_score"], rtol=1e-6)
+    with pytest.raises(KeyError):
+        functions.get_orfs(_Locus("acgtxacgt" * 50))
