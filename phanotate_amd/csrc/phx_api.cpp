@@ -490,7 +490,7 @@ int phx_run(phx_ctx *c) {
         m.sssp_nl = nl_of[k];
         nlmax = std::max(nlmax, m.sssp_nl);
         const size_t lds = phxk_sssp_lds_bytes(m.n_node, m.sssp_nl);
-        m.sssp_mode = c->force_global_sssp ? 0 : lds <= 79 * 1024 ? 1 : lds <= 158 * 1024 ? 2 : 0;
+        m.sssp_mode = c->force_global_sssp ? 0 : lds <= 158 * 1024 ? 1 : 0;
         if (m.n_node > 2) { cls[k][m.sssp_mode].any = true; cls[k][m.sssp_mode].lds = std::max(cls[k][m.sssp_mode].lds, lds); }
     }
     c->tot_edge = e;
@@ -509,14 +509,16 @@ int phx_run(phx_ctx *c) {
         // (disjoint contigs), so all but the first go to side streams and overlap
         StageTimer t(c, ST_SSSP);
         int nlaunch = 0;
-        bool forked = false, used[3] = {false, false, false};
-        for (int k = 0; k < 4; k++)
-            for (int mode = 2; mode >= 0; mode--) // largest-LDS class first: it has the fewest workgroups per CU
+        bool used[3] = {false, false, false};
+        int nclass = 0;
+        for (int k = 0; k < 4; k++) for (int mode = 0; mode < 3; mode++) nclass += cls[k][mode].any ? 1 : 0;
+        if (nclass > 1 && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
+        for (int k = 3; k >= 0; k--) // widest integers first: fewest contigs, longest per-contig time
+            for (int mode = 2; mode >= 0; mode--)
                 if (cls[k][mode].any) {
                     hipStream_t st = s;
                     if (nlaunch > 0 && c->aux[0]) {
                         const int a = (nlaunch - 1) % 3;
-                        if (!forked) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); forked = true; }
                         if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
                         st = c->aux[a];
                     }

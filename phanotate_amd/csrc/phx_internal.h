@@ -18,7 +18,7 @@
 #define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
-#define PHX_MAX_BRIDGE 64
+#define PHX_MAX_BRIDGE 16
 
 // codon classes, in the elif order of functions.py:198-215
 #define CLS_NONE 0

@@ -80,6 +80,21 @@ __device__ __forceinline__ uint32_t block_excl_max(uint32_t v, uint32_t *lds, ui
     return r;
 }
 
+// value of the lane `n` places to the left inside the 16-lane DPP row (own value for the first n lanes)
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ uint64_t dpp_row_shr64(uint64_t x) { return ((uint64_t)dpp_row_shr<N>((uint32_t)(x >> 32)) << 32) | dpp_row_shr<N>((uint32_t)x); }
+// sum over a 16-lane DPP row; the total lands in lane 15 of the row (sub = lane & 15)
+__device__ __forceinline__ uint64_t row16_sum_u64(uint64_t x, int sub) {
+    uint64_t y;
+    y = dpp_row_shr64<1>(x); if (sub >= 1) x += y;
+    y = dpp_row_shr64<2>(x); if (sub >= 2) x += y;
+    y = dpp_row_shr64<4>(x); if (sub >= 4) x += y;
+    y = dpp_row_shr64<8>(x); if (sub >= 8) x += y;
+    return x;
+}
+
 // functions.py:174-178: both strands are counted, so Pa == Pt and Pg == Pc.
 __device__ __forceinline__ double contig_pstop(uint32_t gc, int L) {
     double fa = (double)((uint32_t)L - gc), fg = (double)gc;
@@ -117,7 +132,7 @@ __device__ __forceinline__ uint32_t kmer_lookup(const uint32_t *t6, const uint32
     return 0u;
 }
 
-__global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const DTile *__restrict__ tiles) {
+__global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const DTile *__restrict__ tiles, int n_tiles) {
     __shared__ uint8_t s_code[FW];
     __shared__ uint16_t s_pref[FW];
     __shared__ uint8_t s_W[FW];
@@ -129,17 +144,19 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     __shared__ uint32_t s_gc, s_bad;
 
     const int tid = threadIdx.x;
-    const DTile tile = tiles[blockIdx.x];
+    // the motif tables are loaded once per workgroup; the workgroup then walks over tiles (grid-stride)
+    for (int i = tid; i < 4096; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
+    for (int i = tid; i < 1024; i += PHX_FEAT_THREADS) s_t5[i] = b.rbs_t5[i];
+    if (tid < 256) s_t4[tid] = b.rbs_t4[tid];
+    if (tid < 64) s_t3[tid] = b.rbs_t3[tid];
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+    const DTile tile = tiles[ti];
     DMeta *meta = &b.meta[tile.contig];
     const int L = meta->L;
     const int64_t off = meta->off;
     const int p0 = tile.p0;
     const uint8_t *__restrict__ ascii = b.ascii + off;
-
-    for (int i = tid; i < 4096; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
-    for (int i = tid; i < 1024; i += PHX_FEAT_THREADS) s_t5[i] = b.rbs_t5[i];
-    if (tid < 256) s_t4[tid] = b.rbs_t4[tid];
-    if (tid < 64) s_t3[tid] = b.rbs_t3[tid];
+    __syncthreads(); // the previous tile's LDS is no longer read
     if (tid < 28) s_hist[tid] = 0;
     if (tid == 0) { s_gc = 0; s_bad = 0; }
 
@@ -208,8 +225,9 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     }
     __syncthreads();
 
-    // 4. per-position outputs
+    // 4. per-position outputs (bin 0 of the RBS histogram is by far the most frequent: counted per thread)
     const DParams *P = b.params;
+    uint32_t nz0 = 0;
     for (int j = tid; j < PHX_TILE; j += PHX_FEAT_THREADS) {
         const int p = p0 + j;
         uint32_t cls = 0;
@@ -243,13 +261,15 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
                     uint32_t sc = (s_AF[idx - o] >> (8 * off_class(o))) & 0xffu;
                     bf = sc > bf ? sc : bf;
                 }
-                atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
+                if (bf) atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
+                else nz0++;
             }
             for (int o = 3; o <= 15; o++) {
                 uint32_t sc = (s_AR[idx + o] >> (8 * off_class(o))) & 0xffu;
                 br = sc > br ? sc : br;
             }
-            atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
+            if (br) atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
+            else nz0++;
             b.cls[off + p] = (uint8_t)cls;
             b.gcc[off + p] = (uint8_t)gcc;
             b.cnt[off + p] = (uint8_t)cnt;
@@ -303,6 +323,7 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
         }
     }
     if (mygc) atomicAdd(&s_gc, mygc);
+    if (nz0) atomicAdd(&s_hist[0], nz0);
     if (bad) s_bad = 1;
     __syncthreads();
     if (tid < 28 && s_hist[tid]) atomicAdd(&meta->bg[tid], s_hist[tid]);
@@ -310,6 +331,7 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
         if (s_gc) atomicAdd(&meta->gc, s_gc);
         if (s_bad) atomicMin(&meta->status, PHX_S_BADLETTER);
     }
+    } // tiles
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -547,15 +569,9 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// ORF statistics, one wavefront per ORF (lanes stride the codons, 64-bit packed counters, butterfly reduce):
-// GC-frame class histogram (functions.py:286-298) and p_stop (orfs.py:162-173); then one wavefront per
+// ORF statistics, 16 lanes (one DPP row) per ORF: lanes stride the codons, 64-bit packed counters, DPP row
+// sums: GC-frame class histogram (functions.py:286-298) and p_stop (orfs.py:162-173); then 16 lanes per
 // stop-group for the GC frame plot training of functions.py:261-279.
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((long long)v, d);
-    return v;
-}
-
 __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
@@ -564,20 +580,23 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
     const uint8_t *__restrict__ cnt = b.cnt + off;
     DOrf *orf = b.orf + meta->orf_off;
     const DGrp *grp = b.grp + meta->grp_off;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = threadIdx.x & 15;
+    const int gq = (int)blockIdx.y * (NT / 16) + ((int)threadIdx.x >> 4), gstride = (int)gridDim.y * (NT / 16);
     bool ovf = false;
-    const int wglob = (int)blockIdx.y * (NT / 64) + wv, wstride = (int)gridDim.y * (NT / 64);
-    for (int k = wglob; k < meta->n_orf; k += wstride) {
-        DOrf *r = &orf[k];
+    const int norf = meta->n_orf;
+    for (int k0 = 0; k0 < norf; k0 += gstride) { // uniform trip count: DPP needs the whole row active
+        const int k = k0 + gq;
+        const bool on = k < norf;
+        DOrf *r = &orf[on ? k : 0];
         const int start = r->start, stop = r->stop;
         const bool fwd = r->frame > 0;
         // codons of seq: fwd start..stop (the last one is the stop / last codon, not a sense codon, functions.py:207,290);
         // rev start, start-3, .., stop (functions.py:220,295)
-        const int ncod = (fwd ? stop - start : start - stop) / 3 + 1;
+        const int ncod = on ? (fwd ? stop - start : start - stop) / 3 + 1 : 0;
         if (ncod > 65535) ovf = true;
         uint64_t h0 = 0, h1 = 0, h2 = 0; // classes 0-2, 3-5, 6-8 in 21-bit fields
         uint64_t at = 0, gc_ = 0;        // a | t<<32 ; g | c<<32
-        for (int i = lane; i < ncod; i += 64) {
+        for (int i = sub; i < ncod; i += 16) {
             const int base = fwd ? start + 3 * i : start - 3 * i;
             const uint32_t cb = cnt[base - 1];
             at += (uint64_t)(cb & 3u) | ((uint64_t)((cb >> 2) & 3u) << 32);
@@ -589,9 +608,9 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
                 h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
             }
         }
-        h0 = wave_sum_u64(h0); h1 = wave_sum_u64(h1); h2 = wave_sum_u64(h2);
-        at = wave_sum_u64(at); gc_ = wave_sum_u64(gc_);
-        if (lane == 0) {
+        h0 = row16_sum_u64(h0, sub); h1 = row16_sum_u64(h1, sub); h2 = row16_sum_u64(h2, sub);
+        at = row16_sum_u64(at, sub); gc_ = row16_sum_u64(gc_, sub);
+        if (on && sub == 15) {
             for (int i = 0; i < 3; i++) {
                 r->hist[i] = (uint16_t)((h0 >> (21 * i)) & 0x1fffff);
                 r->hist[3 + i] = (uint16_t)((h1 >> (21 * i)) & 0x1fffff);
@@ -607,35 +626,36 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
         }
     }
     // GC frame plot training: per group, the first ORF longest->shortest whose start codon is 'atg'
-    for (int g = wglob; g < meta->n_grp; g += wstride) {
-        const DGrp G = grp[g];
+    const int ngrp = meta->n_grp;
+    for (int g0 = 0; g0 < ngrp; g0 += gstride) {
+        const int g = g0 + gq;
+        const bool on = g < ngrp;
+        const DGrp G = grp[on ? g : 0];
         // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46): search from the back
         int pick = -1;
-        for (int k0 = G.n - 1; k0 >= 0 && pick < 0; k0 -= 64) {
-            const int k = k0 - lane;
-            const bool atg = k >= 0 && (orf[G.orf_begin + k].flags & 1);
-            const uint64_t m = __ballot(atg);
-            if (m) pick = k0 - (__ffsll((long long)m) - 1);
-        }
-        if (pick < 0) continue;
-        const DOrf *r = &orf[G.orf_begin + pick];
-        const int start = r->start, stop = r->stop;
+        if (on)
+            for (int k = G.n - 1; k >= 0; k--)
+                if (orf[G.orf_begin + k].flags & 1) { pick = k; break; }
         uint64_t mx = 0, mn = 0; // three 16-bit fields each (index 1..3)
-        if (start < stop) {
-            const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
-            for (int base = start + nn + 3 * lane; base < stop - 36; base += 192) {
-                const uint32_t c = gcc[base - 1] & 15u;
-                mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
-            }
-        } else if (stop < start) {
-            const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
-            for (int base = start - nn - 3 * lane; base > stop + 36; base -= 192) {
-                const uint32_t c = (gcc[base - 1] >> 4) & 15u;
-                mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
+        if (pick >= 0) {
+            const DOrf *r = &orf[G.orf_begin + pick];
+            const int start = r->start, stop = r->stop;
+            if (start < stop) {
+                const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
+                for (int base = start + nn + 3 * sub; base < stop - 36; base += 48) {
+                    const uint32_t c = gcc[base - 1] & 15u;
+                    mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
+                }
+            } else if (stop < start) {
+                const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
+                for (int base = start - nn - 3 * sub; base > stop + 36; base -= 48) {
+                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
+                    mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
+                }
             }
         }
-        mx = wave_sum_u64(mx); mn = wave_sum_u64(mn);
-        if (lane == 0)
+        mx = row16_sum_u64(mx, sub); mn = row16_sum_u64(mn, sub);
+        if (pick >= 0 && sub == 15)
             for (int i = 0; i < 3; i++) {
                 const uint32_t a = (uint32_t)((mx >> (16 * i)) & 0xffff), c = (uint32_t)((mn >> (16 * i)) & 0xffff);
                 if (a) atomicAdd(&meta->pmax[i + 1], a);
@@ -845,6 +865,20 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
     const double pgap = contig_pstop(meta->gc, L);
     const int nbr = meta->n_bridge;
     bool parallel = false;
+    // score_gap depends only on (length, direction): tabulate 1/(1-pgap)^(length/3) for length -2..300 once per
+    // workgroup instead of one pow per gap edge; length > 300 is (1-pgap)^100 + length (functions.py:40-41)
+    __shared__ double s_gap[304];
+    __shared__ double s_g100;
+    if (FILL) {
+        for (int i = threadIdx.x; i < 303; i += NT) s_gap[i] = 1.0 / pow(1.0 - pgap, (double)(i - 2) / 3.0);
+        if (threadIdx.x == 0) s_g100 = pow(1.0 - pgap, 100.0);
+        __syncthreads();
+    }
+    auto gap = [&](int length, bool diff) -> double {
+        if (!FILL) return 0.0;
+        if (length > 300) return s_g100 + (double)length;
+        return diff ? s_gap[length + 2] + 20.0 : s_gap[length + 2];
+    };
 
     for (int base = (int)blockIdx.y * NT; base < V; base += (int)gridDim.y * NT) {
         const int v = base + (int)threadIdx.x;
@@ -856,7 +890,7 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                 // functions.py:449-452
                 for (int u = ncds - 1; u >= 0 && L - npos[u] <= 2000; u--) {
                     const int t = NTYPE(ninfo[u]), f = NFRAME(ninfo[u]);
-                    if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, score_gap(L - npos[u], false, pgap));
+                    if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, gap(L - npos[u], false));
                 }
             } else {
                 const int t = NTYPE(ninfo[v]), f = NFRAME(ninfo[v]), pos = npos[v];
@@ -873,7 +907,7 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                 } else {
                     const int my_other = nother[v];
                     const double my_o = no[v];
-                    if (pos <= 2000) emit_edge<FILL>(sink, SRC, score_gap(pos, false, pgap)); // functions.py:445-448
+                    if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
                     // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
                     for (int u = v - 1; u >= 0; u--) {
                         const int d = pos - npos[u];
@@ -881,11 +915,11 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                         if (d <= 0) continue;
                         const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
                         if (t == 0) { // v = forward start
-                            if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, score_gap(d - 3, false, pgap));
-                            else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, score_gap(d - 3, true, pgap));
+                            if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
+                            else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, gap(d - 3, true));
                         } else { // v = reverse stop
-                            if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, score_gap(d - 3, false, pgap));
-                            else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, score_gap(d - 3, true, pgap));
+                            if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
+                            else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, true));
                         }
                     }
                     // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
@@ -931,7 +965,7 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                             }
                             if (hit) {
                                 if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
-                                emit_edge<FILL>(sink, u, score_gap(d - 3, diff, pgap));
+                                emit_edge<FILL>(sink, u, gap(d - 3, diff));
                             }
                         }
                     }
@@ -1205,7 +1239,7 @@ __global__ void k_path(DBatch b) {
 // once at the end (lowest-index tight in-edge), which is also what makes ties schedule-independent.
 #define SW_ADV 32
 #define SW_MAX 64
-#define SW_ECAP 1536
+#define SW_ECAP 1024
 #ifndef SW_LPN
 #define SW_LPN 8 // lanes per node (4, 8 or 16; a DPP row has 16 lanes)
 #endif
@@ -1234,9 +1268,6 @@ __device__ __forceinline__ WInt<NL> wi_min_bf(const WInt<NL> &a, const WInt<NL> 
     for (int i = 0; i < NL; i++) r.v[i] = lt ? b.v[i] : a.v[i];
     return r;
 }
-// value of the lane `n` places to the left inside the 16-lane DPP row (own value for the first n lanes)
-template <int N>
-__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x110 + N, 0xf, 0xf, false); }
 template <int N, int NL>
 __device__ __forceinline__ WInt<NL> wi_row_shr(const WInt<NL> &a) {
     WInt<NL> r;
@@ -1266,6 +1297,11 @@ __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
     return x;
 }
 
+// Distances of the last SW_RING nodes (node ids are position-sorted, so this is a sliding window over the
+// contig) are kept in an LDS ring; every improvement is also written through to the global array, which
+// serves the rare reads outside the ring (an ORF edge longer than ~SW_RING nodes, or a backward edge from
+// beyond a capped look-ahead).  LDS use is independent of the contig size.
+#define SW_RING 1024
 template <int NL>
 __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -1281,19 +1317,21 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
     const uint32_t *esrc = b.esrc + meta->edge_off;
     const double *ew = b.ew + meta->edge_off;
     const int32_t *npos = b.npos + meta->node_off;
-    // LDS carve: dist V*NL u64 | tile weights SW_ECAP*NL u64 | tile sources SW_ECAP u32
-    // (after convergence the tile area is reused for the parent node of every node)
-    uint64_t *dist = (uint64_t *)smem;
-    uint64_t *tw = dist + (size_t)V * NL;
+    uint64_t *gdist = b.dist + (size_t)meta->node_off * b.dist_stride;
+    // LDS carve: ring (SW_RING+1)*NL u64 (slot SW_RING = the constant 0 of the source) | tile weights SW_ECAP*NL u64 |
+    // tile source slots SW_ECAP u32.  After convergence the whole area is reused for one parent per node.
+    uint64_t *ring = (uint64_t *)smem;
+    uint64_t *tw = ring + (size_t)(SW_RING + 1) * NL;
     uint32_t *tsrc = (uint32_t *)(tw + (size_t)SW_ECAP * NL);
-    uint32_t *psrc = (uint32_t *)tw;
+    const size_t lds_words = (size_t)(SW_RING + 1) * NL * 2 + (size_t)SW_ECAP * NL * 2 + SW_ECAP; // 32-bit words available
     for (int v = tid; v < V; v += SW_THREADS) {
         WInt<NL> d;
 #pragma unroll
         for (int i = 0; i < NL; i++) d.v[i] = 0;
         if (v != SRC) d.v[NL - 1] = WBIG_TOP;
-        wi_store<NL>(dist + (size_t)v * NL, d);
+        wi_store<NL>(gdist + (size_t)v * NL, d);
     }
+    if (tid < NL) ring[(size_t)SW_RING * NL + tid] = 0;
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
     const int node_l = tid / SW_LPN, sub = tid % SW_LPN;
@@ -1304,6 +1342,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
     bool any = true, bad = false;
     while (any && !bad) {
         any = false;
+        int loaded = 0; // nodes [max(0, loaded - SW_RING), loaded) are in the ring
         for (int v0 = 0; v0 < V && !bad;) {
             // ---- window [v0, v1): SW_ADV nodes to advance by, plus look-ahead ----
             const int vadv = v0 + SW_ADV < V ? v0 + SW_ADV : V;
@@ -1321,14 +1360,26 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
             const int nwin = v1 - v0;
             const int adv = vadv < v1 ? vadv : v1; // if the edge cap cut the window short, advance less
             if (tid <= nwin) s_off[tid] = in_off[v0 + tid];
+            // nodes that enter the ring with this window bring their current distance from global memory
+            for (int v = loaded + tid; v < v1; v += SW_THREADS) wi_store<NL>(ring + (size_t)(v & (SW_RING - 1)) * NL, wi_load<NL>(gdist + (size_t)v * NL));
+            loaded = v1 > loaded ? v1 : loaded;
             __syncthreads();
             const uint32_t e0 = s_off[0];
             const int ne = (int)(s_off[nwin] - e0);
             const bool tiled = ne <= SW_ECAP; // false only if a single node has more in-edges than the tile holds
             if (tiled)
                 for (int i = tid; i < ne; i += SW_THREADS) {
-                    tsrc[i] = esrc[e0 + i];
-                    wi_store<NL>(tw + (size_t)i * NL, wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0)));
+                    const uint32_t u = esrc[e0 + i];
+                    WInt<NL> w = wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0));
+                    // source slot: a ring slot, or the constant-zero slot (the source node; and sources outside the
+                    // ring, whose distance cannot change while this window iterates and is folded into the weight)
+                    uint32_t sl = SW_RING;
+                    if (u != (uint32_t)SRC) {
+                        if ((int)u < loaded && (int)u + SW_RING >= loaded) sl = u & (SW_RING - 1);
+                        else w = wi_add<NL>(w, wi_load<NL>(gdist + (size_t)u * NL));
+                    }
+                    tsrc[i] = sl;
+                    wi_store<NL>(tw + (size_t)i * NL, w);
                 }
             __syncthreads();
 #ifdef SW_PROFILE
@@ -1339,6 +1390,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
             const bool act = node_l < nwin;
             const int ia = act ? (int)(s_off[node_l] - e0) + sub : 0;
             const int ib = act ? (int)(s_off[node_l + 1] - e0) : 0;
+            uint64_t *myslot = ring + (size_t)(v & (SW_RING - 1)) * NL;
             int inner = 0;
             bool chg = true;
             while (chg) {
@@ -1346,25 +1398,30 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
 #pragma unroll
                 for (int i = 0; i < NL; i++) d0.v[i] = 0;
                 d0.v[NL - 1] = WBIG_TOP;
-                if (act) d0 = wi_load<NL>(dist + (size_t)v * NL);
+                if (act) d0 = wi_load<NL>(myslot);
                 WInt<NL> best = d0;
                 if (tiled) {
                     for (int i = ia; i < ib; i += SW_LPN) {
-                        const uint32_t u = tsrc[i];
-                        const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)u * NL), wi_load<NL>(tw + (size_t)i * NL));
-                        best = wi_min_bf<NL>(best, cand);
+                        best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)tsrc[i] * NL), wi_load<NL>(tw + (size_t)i * NL)));
                     }
                 } else {
                     for (int i = ia; i < ib; i += SW_LPN) {
                         const uint32_t u = esrc[e0 + i];
-                        const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)u * NL), wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0)));
-                        best = wi_min_bf<NL>(best, cand);
+                        WInt<NL> du;
+                        if (u == (uint32_t)SRC) du = wi_load<NL>(ring + (size_t)SW_RING * NL);
+                        else if ((int)u < loaded && (int)u + SW_RING >= loaded) du = wi_load<NL>(ring + (size_t)(u & (SW_RING - 1)) * NL);
+                        else du = wi_load<NL>(gdist + (size_t)u * NL);
+                        best = wi_min_bf<NL>(best, wi_add<NL>(du, wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0))));
                     }
                 }
                 best = wi_row_min<NL>(best, sub);
                 const bool improved = act && sub == SW_LPN - 1 && wi_lt_bf<NL>(best, d0);
                 __syncthreads(); // every read of this iteration is done
-                if (improved) { wi_store<NL>(dist + (size_t)v * NL, best); s_flag[it & 1] = 1; }
+                if (improved) {
+                    wi_store<NL>(myslot, best);
+                    wi_store<NL>(gdist + (size_t)v * NL, best); // write-through
+                    s_flag[it & 1] = 1;
+                }
                 if (tid == 0) s_flag[(it + 1) & 1] = 0;
                 __syncthreads();
                 chg = s_flag[it & 1] != 0;
@@ -1380,25 +1437,27 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
         if (++sweeps > V + 2) bad = true;
     }
     __syncthreads();
-    // ---- parents: the tight in-edge with the lowest index (canonical tie-break) ----
+    // ---- parents: the tight in-edge with the lowest index (canonical tie-break); distances now come from global ----
     uint32_t *gpe = (uint32_t *)(b.parent + meta->node_off);
+    const bool ps_lds = (size_t)V <= lds_words; // else (very large contigs) the walk below chases parent edges in global memory
+    uint32_t *psrc = (uint32_t *)smem;
+    __syncthreads();
     for (int vb = 0; vb < V; vb += SW_MAX) {
         const int v = vb + node_l;
         uint32_t be = PE_NONE;
         if (v < V) {
-            const WInt<NL> dv = wi_load<NL>(dist + (size_t)v * NL);
+            const WInt<NL> dv = wi_load<NL>(gdist + (size_t)v * NL);
             if (!wi_unreached<NL>(dv)) {
                 const uint32_t e1 = in_off[v + 1];
                 for (uint32_t e = in_off[v] + sub; e < e1; e += SW_LPN) {
-                    const WInt<NL> cand = wi_add<NL>(wi_load<NL>(dist + (size_t)esrc[e] * NL), wi_from_double<NL>(trunc(ew[e] * 1000.0)));
+                    const WInt<NL> cand = wi_add<NL>(wi_load<NL>(gdist + (size_t)esrc[e] * NL), wi_from_double<NL>(trunc(ew[e] * 1000.0)));
                     if (wi_eq<NL>(cand, dv) && e < be) be = e;
                 }
             }
         }
         be = u32_row_min(be, sub);
-        if (v < V && sub == SW_LPN - 1) { gpe[v] = be; psrc[v] = be == PE_NONE ? PE_NONE : esrc[be]; }
+        if (v < V && sub == SW_LPN - 1) { gpe[v] = be; if (ps_lds) psrc[v] = be == PE_NONE ? PE_NONE : esrc[be]; }
     }
-    if (tid < NL) (b.dist + (size_t)meta->node_off * b.dist_stride)[(size_t)TGT * NL + tid] = dist[(size_t)TGT * NL + tid];
     __syncthreads();
     // ---- path (phanotate.py:64-67) and genes (phanotate.py:71-76, locus.py:29-37) ----
     int32_t *path = b.path + meta->node_off;
@@ -1408,14 +1467,14 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
         meta->n_genes = 0; meta->n_path = 0; meta->gene_off = 0;
         int np = -1;
         if (bad) meta->status = PHX_S_NEGCYCLE;
-        else if (wi_unreached<NL>(wi_load<NL>(dist + (size_t)TGT * NL))) meta->status = PHX_S_NOPATH;
+        else if (wi_unreached<NL>(wi_load<NL>(gdist + (size_t)TGT * NL))) meta->status = PHX_S_NOPATH;
         else {
             int n = 0;
-            for (int v = TGT; v != SRC && n <= V; v = (int)psrc[v]) n++;
+            for (int v = TGT; v != SRC && n <= V; v = ps_lds ? (int)psrc[v] : (int)esrc[gpe[v]]) n++;
             if (n > V) meta->status = PHX_S_NEGCYCLE;
             else {
                 int k = n;
-                for (int v = TGT;; v = (int)psrc[v]) { path[k--] = v; if (v == SRC || k < 0) break; }
+                for (int v = TGT;; v = ps_lds ? (int)psrc[v] : (int)esrc[gpe[v]]) { path[k--] = v; if (v == SRC || k < 0) break; }
                 meta->n_path = n + 1;
                 np = n / 2; // shortest_path[1:] taken two at a time (file_handling.pairwise)
                 meta->n_genes = np;
@@ -1461,7 +1520,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
 // launchers
 extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
-    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles);
+    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
 }
 void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
@@ -1487,9 +1546,8 @@ void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
 }
 
 size_t phxk_sssp_lds_bytes(int V, int nl) {
-    size_t tile = (size_t)SW_ECAP * ((size_t)nl * 8 + 4);
-    if (tile < (size_t)V * 4) tile = (size_t)V * 4; // the tile area later holds one parent per node
-    return (size_t)V * nl * 8 + tile + 64;
+    (void)V; // the LDS kernel keeps a fixed-size ring of distances: its footprint does not depend on the contig
+    return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + 64;
 }
 
 // mode 0: global-memory kernel (+ k_path); mode 1/2: LDS kernel with `lds_bytes` of dynamic LDS
