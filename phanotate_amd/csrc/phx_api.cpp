@@ -535,6 +535,7 @@ int phx_run(phx_ctx *c) {
     }
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
+    if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_SSSP"))
         for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pad2 * 0.01);
     c->ran = true;

@@ -1301,13 +1301,25 @@ __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
 // contig) are kept in an LDS ring; every improvement is also written through to the global array, which
 // serves the rare reads outside the ring (an ORF edge longer than ~SW_RING nodes, or a backward edge from
 // beyond a capped look-ahead).  LDS use is independent of the contig size.
+//
+// Window k starts at node 32k; its size (32 + look-ahead, <= 64) is planned once per contig.  While window k
+// iterates out of LDS, the in-edge tile, the node types, the ring fill-in and the in-edge offsets of window
+// k+1 are already in flight into registers, so global-memory latency stays off the critical path.
 #define SW_RING 1024
+#define SW_EPT ((SW_ECAP + SW_THREADS - 1) / SW_THREADS) // tile edges prefetched per thread
+#ifndef SW_RC
+#define SW_RC 1 // in-edges per lane and node kept in registers
+#endif
+#ifndef SW_WPS
+#define SW_WPS 6 // wavefronts per SIMD the register allocation must allow (workgroups/CU = SW_WPS * 256 / SW_THREADS)
+#endif
 template <int NL>
-__global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
+__global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int mode) {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_flag[2];
-    __shared__ int s_v1, s_np;
-    __shared__ uint32_t s_off[SW_MAX + 1];
+    __shared__ int s_np, s_nclose, s_viol;
+    __shared__ uint32_t s_off[2][SW_MAX + 1];
+    __shared__ uint8_t s_list[SW_MAX];
     DMeta *meta = &b.meta[blockIdx.x];
     const int V = meta->n_node;
     if (meta->status < 0 || V <= 2 || meta->sssp_nl != NL || meta->sssp_mode != mode) return;
@@ -1317,13 +1329,17 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
     const uint32_t *esrc = b.esrc + meta->edge_off;
     const double *ew = b.ew + meta->edge_off;
     const int32_t *npos = b.npos + meta->node_off;
+    const int32_t *ninfo = b.ninfo + meta->node_off;
     uint64_t *gdist = b.dist + (size_t)meta->node_off * b.dist_stride;
     // LDS carve: ring (SW_RING+1)*NL u64 (slot SW_RING = the constant 0 of the source) | tile weights SW_ECAP*NL u64 |
-    // tile source slots SW_ECAP u32.  After convergence the whole area is reused for one parent per node.
+    // tile source slots SW_ECAP u32 | window plan nW bytes.  After convergence the ring+tile area is reused for one
+    // parent per node.
     uint64_t *ring = (uint64_t *)smem;
     uint64_t *tw = ring + (size_t)(SW_RING + 1) * NL;
     uint32_t *tsrc = (uint32_t *)(tw + (size_t)SW_ECAP * NL);
-    const size_t lds_words = (size_t)(SW_RING + 1) * NL * 2 + (size_t)SW_ECAP * NL * 2 + SW_ECAP; // 32-bit words available
+    uint8_t *plan = (uint8_t *)(tsrc + SW_ECAP);
+    const size_t lds_words = (size_t)(SW_RING + 1) * NL * 2 + (size_t)SW_ECAP * NL * 2 + SW_ECAP; // 32-bit words before the plan
+    const int nW = (V + SW_ADV - 1) / SW_ADV;
     for (int v = tid; v < V; v += SW_THREADS) {
         WInt<NL> d;
 #pragma unroll
@@ -1332,133 +1348,227 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
         wi_store<NL>(gdist + (size_t)v * NL, d);
     }
     if (tid < NL) ring[(size_t)SW_RING * NL + tid] = 0;
+#ifdef SW_CENSUS
+    if (tid == 0) { uint32_t c = atomicAdd(b.gene_total + 1, 1u) + 1; atomicMax(b.gene_total + 2, c); }
+#endif
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+    // ---- plan: size of every window = SW_ADV nodes to advance by + the nodes of the next 500 bp (<= SW_MAX, tile cap) ----
+    for (int k = tid >> 6; k < nW; k += SW_THREADS / 64) {
+        const int v0 = k * SW_ADV, lane = tid & 63;
+        const int vadv = v0 + SW_ADV < V ? v0 + SW_ADV : V;
+        const int idx = v0 + lane;
+        bool ok = idx < V;
+        if (ok && idx >= vadv) ok = idx < ncds && vadv - 1 < ncds && npos[idx] < npos[vadv - 1] + 500 && in_off[idx + 1] - in_off[v0] <= SW_ECAP;
+        const uint64_t m = __ballot(ok);
+        const int cnt = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
+        if (lane == 0) plan[k] = (uint8_t)cnt; // >= vadv - v0 >= 1
+    }
     __syncthreads();
     const int node_l = tid / SW_LPN, sub = tid % SW_LPN;
 #ifdef SW_PROFILE
     long long t_setup = 0, t_iter = 0, t_mark = wall_clock64();
 #endif
     int sweeps = 0, it = 0;
-    bool any = true, bad = false;
-    while (any && !bad) {
-        any = false;
+    bool again = true, bad = false;
+    uint32_t *gpe = (uint32_t *)(b.parent + meta->node_off);
+    const bool ps_lds = (size_t)V <= lds_words; // else (very large contigs) the final walk chases parent edges in global memory
+    uint32_t *psrc = (uint32_t *)smem;
+    while (again && !bad) {
         int loaded = 0; // nodes [max(0, loaded - SW_RING), loaded) are in the ring
-        for (int v0 = 0; v0 < V && !bad;) {
-            // ---- window [v0, v1): SW_ADV nodes to advance by, plus look-ahead ----
-            const int vadv = v0 + SW_ADV < V ? v0 + SW_ADV : V;
-            if (tid < 64) {
-                const int idx = v0 + tid;
-                bool ok = idx < V;
-                if (ok && idx >= vadv) ok = idx < ncds && vadv - 1 < ncds && npos[idx] < npos[vadv - 1] + 500;
-                if (ok && idx > v0) ok = in_off[idx + 1] - in_off[v0] <= SW_ECAP; // the first node always fits (in-degree << SW_ECAP)
-                const uint64_t m = __ballot(ok);
-                const int cnt = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
-                if (tid == 0) s_v1 = v0 + (cnt < 1 ? 1 : cnt);
+        if (tid < NL) ring[(size_t)SW_RING * NL + tid] = 0; // the constant-zero slot (the LDS is reused by the pass below)
+        if (tid == 0) s_viol = 0;
+        __syncthreads();
+        // registers that carry window k+1's data while window k iterates
+        uint32_t r_src[SW_EPT];
+        double r_w[SW_EPT];
+        uint32_t r_offn = 0;
+        int r_type = 0;
+        WInt<NL> r_ring;
+        // prologue: window 0
+        {
+            const int nw0 = plan[0];
+            if (tid <= nw0) s_off[0][tid] = in_off[tid];
+            __syncthreads();
+            const uint32_t e0n = s_off[0][0];
+            const int nen = (int)(s_off[0][nw0] - e0n);
+            r_type = tid < nw0 ? ninfo[tid] : 0;
+            r_ring = wi_load<NL>(gdist + (size_t)(tid < nw0 ? tid : 0) * NL);
+            r_offn = (nW > 1 && tid <= plan[1]) ? in_off[SW_ADV + tid] : 0u;
+#pragma unroll
+            for (int j = 0; j < SW_EPT; j++) {
+                const int i = tid + j * SW_THREADS;
+                const bool on = nen <= SW_ECAP && i < nen;
+                r_src[j] = on ? esrc[e0n + i] : 0u;
+                r_w[j] = on ? ew[e0n + i] : 0.0;
+            }
+        }
+        for (int k = 0; k < nW && !bad; k++) {
+            const int cur = k & 1;
+            const int v0 = k * SW_ADV;
+            const int nwin = plan[k];
+            const int v1 = v0 + nwin;
+            // ---- commit the prefetched registers of this window to LDS ----
+            if (k + 1 < nW && tid <= plan[k + 1]) s_off[cur ^ 1][tid] = r_offn;
+            if (tid < 64) { // split the window into close nodes (ORF-edge targets) and open nodes (connector targets)
+                const int t = NTYPE(r_type), f = NFRAME(r_type);
+                const bool isclose = tid < nwin && ((t == 1 && f > 0) || (t == 0 && f < 0));
+                const uint64_t mc = __ballot(isclose);
+                const uint64_t mo = __ballot(tid < nwin && !isclose);
+                const uint64_t below = tid ? (~0ull >> (64 - tid)) : 0ull;
+                const int nc = __popcll(mc);
+                if (tid < nwin) s_list[isclose ? __popcll(mc & below) : nc + __popcll(mo & below)] = (uint8_t)tid;
+                if (tid == 0) s_nclose = nc;
+            }
+            // nodes that enter the ring with this window bring their current distance from global memory
+            if (loaded + tid < v1) wi_store<NL>(ring + (size_t)((loaded + tid) & (SW_RING - 1)) * NL, r_ring);
+            loaded = v1 > loaded ? v1 : loaded;
+            const uint32_t e0 = s_off[cur][0];
+            const int ne = (int)(s_off[cur][nwin] - e0);
+            const bool tiled = ne <= SW_ECAP; // false only if the SW_ADV advance nodes alone exceed the tile
+            if (tiled) {
+#pragma unroll
+                for (int j = 0; j < SW_EPT; j++) {
+                    const int i = tid + j * SW_THREADS;
+                    if (i < ne) {
+                        const uint32_t u = r_src[j];
+                        WInt<NL> w = wi_from_double<NL>(trunc(r_w[j] * 1000.0));
+                        // source slot: a ring slot, or the constant-zero slot (the source node; and sources outside the
+                        // ring, whose distance cannot change while this window iterates and is folded into the weight)
+                        uint32_t sl = SW_RING;
+                        if (u != (uint32_t)SRC) {
+                            if ((int)u < loaded && (int)u + SW_RING >= loaded) sl = u & (SW_RING - 1);
+                            else w = wi_add<NL>(w, wi_load<NL>(gdist + (size_t)u * NL));
+                        }
+                        tsrc[i] = sl;
+                        wi_store<NL>(tw + (size_t)i * NL, w);
+                    }
+                }
             }
             __syncthreads();
-            const int v1 = s_v1;
-            const int nwin = v1 - v0;
-            const int adv = vadv < v1 ? vadv : v1; // if the edge cap cut the window short, advance less
-            if (tid <= nwin) s_off[tid] = in_off[v0 + tid];
-            // nodes that enter the ring with this window bring their current distance from global memory
-            for (int v = loaded + tid; v < v1; v += SW_THREADS) wi_store<NL>(ring + (size_t)(v & (SW_RING - 1)) * NL, wi_load<NL>(gdist + (size_t)v * NL));
-            loaded = v1 > loaded ? v1 : loaded;
-            __syncthreads();
-            const uint32_t e0 = s_off[0];
-            const int ne = (int)(s_off[nwin] - e0);
-            const bool tiled = ne <= SW_ECAP; // false only if a single node has more in-edges than the tile holds
-            if (tiled)
-                for (int i = tid; i < ne; i += SW_THREADS) {
-                    const uint32_t u = esrc[e0 + i];
-                    WInt<NL> w = wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0));
-                    // source slot: a ring slot, or the constant-zero slot (the source node; and sources outside the
-                    // ring, whose distance cannot change while this window iterates and is folded into the weight)
-                    uint32_t sl = SW_RING;
-                    if (u != (uint32_t)SRC) {
-                        if ((int)u < loaded && (int)u + SW_RING >= loaded) sl = u & (SW_RING - 1);
-                        else w = wi_add<NL>(w, wi_load<NL>(gdist + (size_t)u * NL));
-                    }
-                    tsrc[i] = sl;
-                    wi_store<NL>(tw + (size_t)i * NL, w);
+            // ---- put window k+1 in flight ----
+            if (k + 1 < nW) {
+                const int v0n = v0 + SW_ADV, nwn = plan[k + 1], v1n = v0n + nwn;
+                const uint32_t e0n = s_off[cur ^ 1][0];
+                const int nen = (int)(s_off[cur ^ 1][nwn] - e0n);
+                r_type = tid < nwn ? ninfo[v0n + tid] : 0;
+                r_ring = wi_load<NL>(gdist + (size_t)(loaded + tid < v1n ? loaded + tid : 0) * NL);
+                r_offn = (k + 2 < nW && tid <= plan[k + 2]) ? in_off[v0n + SW_ADV + tid] : 0u;
+#pragma unroll
+                for (int j = 0; j < SW_EPT; j++) {
+                    const int i = tid + j * SW_THREADS;
+                    const bool on = nen <= SW_ECAP && i < nen;
+                    r_src[j] = on ? esrc[e0n + i] : 0u;
+                    r_w[j] = on ? ew[e0n + i] : 0.0;
                 }
-            __syncthreads();
+            }
 #ifdef SW_PROFILE
             { long long t = wall_clock64(); t_setup += t - t_mark; t_mark = t; }
 #endif
             // ---- iterate the window to its fixed point ----
-            const int v = v0 + node_l;
-            const bool act = node_l < nwin;
-            const int ia = act ? (int)(s_off[node_l] - e0) + sub : 0;
-            const int ib = act ? (int)(s_off[node_l + 1] - e0) : 0;
-            uint64_t *myslot = ring + (size_t)(v & (SW_RING - 1)) * NL;
-            int inner = 0;
-            bool chg = true;
-            while (chg) {
-                WInt<NL> d0;
+            // The graph is bipartite: close nodes (forward stops, reverse starts) are reached by ORF edges from open
+            // nodes only; open nodes (forward starts, reverse stops, target) by connector edges from close nodes and the
+            // source only.  One round = phase A (all close nodes) then phase B (all open nodes): inside a phase nobody
+            // reads what anybody writes, so results are written at once, and a round advances two hops.
+            const int nclose = s_nclose, nopen = nwin - nclose;
+            const bool actA = node_l < nclose, actB = node_l < nopen;
+            const int lA = actA ? s_list[node_l] : 0, lB = actB ? s_list[nclose + node_l] : 0;
+            const int iaA = actA ? (int)(s_off[cur][lA] - e0) + sub : 0, ibA = actA ? (int)(s_off[cur][lA + 1] - e0) : 0;
+            const int iaB = actB ? (int)(s_off[cur][lB] - e0) + sub : 0, ibB = actB ? (int)(s_off[cur][lB + 1] - e0) : 0;
+            uint64_t *slotA = ring + (size_t)((v0 + lA) & (SW_RING - 1)) * NL, *slotB = ring + (size_t)((v0 + lB) & (SW_RING - 1)) * NL;
+            uint64_t *gA = gdist + (size_t)(v0 + lA) * NL, *gB = gdist + (size_t)(v0 + lB) * NL;
+            // the first SW_RC in-edges of this lane stay in registers for all rounds of the window
+            uint32_t csA[SW_RC], csB[SW_RC];
+            WInt<NL> cwA[SW_RC], cwB[SW_RC];
 #pragma unroll
-                for (int i = 0; i < NL; i++) d0.v[i] = 0;
-                d0.v[NL - 1] = WBIG_TOP;
-                if (act) d0 = wi_load<NL>(myslot);
-                WInt<NL> best = d0;
-                if (tiled) {
-                    for (int i = ia; i < ib; i += SW_LPN) {
-                        best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)tsrc[i] * NL), wi_load<NL>(tw + (size_t)i * NL)));
+            for (int j = 0; j < SW_RC; j++) {
+                WInt<NL> big;
+#pragma unroll
+                for (int i = 0; i < NL; i++) big.v[i] = 0;
+                big.v[NL - 1] = WBIG_TOP;
+                const int ia = iaA + j * SW_LPN, ib = iaB + j * SW_LPN;
+                const bool oa = tiled && ia < ibA, ob = tiled && ib < ibB;
+                csA[j] = oa ? tsrc[ia] : (uint32_t)SW_RING;
+                cwA[j] = oa ? wi_load<NL>(tw + (size_t)ia * NL) : big;
+                csB[j] = ob ? tsrc[ib] : (uint32_t)SW_RING;
+                cwB[j] = ob ? wi_load<NL>(tw + (size_t)ib * NL) : big;
+            }
+            // A phase that changes nothing ends the window: the next phase would read exactly what it read last time.
+            // (Exception: the window's very first phase A — phase B has not seen this window's close nodes yet.)
+            int inner = 0;
+            for (int ph = 0;; ph ^= 1) {
+                const bool act = ph ? actB : actA;
+                // node groups are compacted per phase: a wavefront whose first group is already past the phase's node
+                // count has nothing to do and goes straight to the barrier (wave-uniform branch)
+                if ((tid & ~63) / SW_LPN < (ph ? nopen : nclose)) {
+                    const int ia = ph ? iaB : iaA, ib = ph ? ibB : ibA;
+                    uint64_t *myslot = ph ? slotB : slotA;
+                    WInt<NL> d0;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) d0.v[i] = 0;
+                    d0.v[NL - 1] = WBIG_TOP;
+                    if (act) d0 = wi_load<NL>(myslot);
+                    WInt<NL> best = d0;
+                    if (tiled) {
+#pragma unroll
+                        for (int j = 0; j < SW_RC; j++)
+                            best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)(ph ? csB[j] : csA[j]) * NL), ph ? cwB[j] : cwA[j]));
+                        for (int i = ia + SW_RC * SW_LPN; i < ib; i += SW_LPN)
+                            best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)tsrc[i] * NL), wi_load<NL>(tw + (size_t)i * NL)));
+                    } else {
+                        for (int i = ia; i < ib; i += SW_LPN) {
+                            const uint32_t u = esrc[e0 + i];
+                            WInt<NL> du;
+                            if (u == (uint32_t)SRC) du = wi_load<NL>(ring + (size_t)SW_RING * NL);
+                            else if ((int)u < loaded && (int)u + SW_RING >= loaded) du = wi_load<NL>(ring + (size_t)(u & (SW_RING - 1)) * NL);
+                            else du = wi_load<NL>(gdist + (size_t)u * NL);
+                            best = wi_min_bf<NL>(best, wi_add<NL>(du, wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0))));
+                        }
                     }
-                } else {
-                    for (int i = ia; i < ib; i += SW_LPN) {
-                        const uint32_t u = esrc[e0 + i];
-                        WInt<NL> du;
-                        if (u == (uint32_t)SRC) du = wi_load<NL>(ring + (size_t)SW_RING * NL);
-                        else if ((int)u < loaded && (int)u + SW_RING >= loaded) du = wi_load<NL>(ring + (size_t)(u & (SW_RING - 1)) * NL);
-                        else du = wi_load<NL>(gdist + (size_t)u * NL);
-                        best = wi_min_bf<NL>(best, wi_add<NL>(du, wi_from_double<NL>(trunc(ew[e0 + i] * 1000.0))));
+                    best = wi_row_min<NL>(best, sub);
+                    if (act && sub == SW_LPN - 1 && wi_lt_bf<NL>(best, d0)) {
+                        wi_store<NL>(myslot, best);
+                        wi_store<NL>(ph ? gB : gA, best); // write-through
+                        s_flag[it & 1] = 1;
                     }
-                }
-                best = wi_row_min<NL>(best, sub);
-                const bool improved = act && sub == SW_LPN - 1 && wi_lt_bf<NL>(best, d0);
-                __syncthreads(); // every read of this iteration is done
-                if (improved) {
-                    wi_store<NL>(myslot, best);
-                    wi_store<NL>(gdist + (size_t)v * NL, best); // write-through
-                    s_flag[it & 1] = 1;
                 }
                 if (tid == 0) s_flag[(it + 1) & 1] = 0;
                 __syncthreads();
-                chg = s_flag[it & 1] != 0;
+                const bool chg = s_flag[it & 1] != 0;
                 it++;
-                any = any || chg;
-                if (++inner > SW_MAX + 8) { bad = true; break; }
+                if (!chg && (ph == 1 || inner > 0)) break;
+                if (++inner > 2 * SW_MAX + 16) { bad = true; break; }
             }
 #ifdef SW_PROFILE
             { long long t = wall_clock64(); t_iter += t - t_mark; t_mark = t; }
 #endif
-            v0 = adv > v0 ? adv : v0 + 1;
         }
         if (++sweeps > V + 2) bad = true;
-    }
-    __syncthreads();
-    // ---- parents: the tight in-edge with the lowest index (canonical tie-break); distances now come from global ----
-    uint32_t *gpe = (uint32_t *)(b.parent + meta->node_off);
-    const bool ps_lds = (size_t)V <= lds_words; // else (very large contigs) the walk below chases parent edges in global memory
-    uint32_t *psrc = (uint32_t *)smem;
-    __syncthreads();
-    for (int vb = 0; vb < V; vb += SW_MAX) {
-        const int v = vb + node_l;
-        uint32_t be = PE_NONE;
-        if (v < V) {
-            const WInt<NL> dv = wi_load<NL>(gdist + (size_t)v * NL);
-            if (!wi_unreached<NL>(dv)) {
+        __syncthreads();
+        // ---- verification + parents in one pass over every in-edge (distances from global memory) ----
+        // A node that some in-edge could still improve means the sweep missed a backward dependency that reaches
+        // beyond a window's look-ahead: sweep again.  Otherwise the distances are the fixed point and every node
+        // takes its tight in-edge with the lowest index as parent (canonical tie-break).
+        for (int vb = 0; vb < V; vb += SW_MAX) {
+            const int v = vb + node_l;
+            uint32_t be = PE_NONE;
+            bool viol = false;
+            if (v < V) {
+                const WInt<NL> dv = wi_load<NL>(gdist + (size_t)v * NL);
                 const uint32_t e1 = in_off[v + 1];
                 for (uint32_t e = in_off[v] + sub; e < e1; e += SW_LPN) {
                     const WInt<NL> cand = wi_add<NL>(wi_load<NL>(gdist + (size_t)esrc[e] * NL), wi_from_double<NL>(trunc(ew[e] * 1000.0)));
-                    if (wi_eq<NL>(cand, dv) && e < be) be = e;
+                    if (wi_lt_bf<NL>(cand, dv)) viol = true;
+                    if (wi_eq<NL>(cand, dv) && e < be && !wi_unreached<NL>(dv)) be = e;
                 }
             }
+            be = u32_row_min(be, sub);
+            if (viol) s_viol = 1;
+            if (v < V && sub == SW_LPN - 1) { gpe[v] = be; if (ps_lds) psrc[v] = be == PE_NONE ? PE_NONE : esrc[be]; }
         }
-        be = u32_row_min(be, sub);
-        if (v < V && sub == SW_LPN - 1) { gpe[v] = be; if (ps_lds) psrc[v] = be == PE_NONE ? PE_NONE : esrc[be]; }
+        __syncthreads();
+        again = s_viol != 0;
+        __syncthreads();
     }
-    __syncthreads();
     // ---- path (phanotate.py:64-67) and genes (phanotate.py:71-76, locus.py:29-37) ----
     int32_t *path = b.path + meta->node_off;
     if (tid == 0) {
@@ -1482,6 +1592,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sssp_lds(DBatch b, int mode) {
             }
         }
         s_np = np;
+#ifdef SW_CENSUS
+        atomicSub(b.gene_total + 1, 1u);
+#endif
 #ifdef SW_PROFILE
         { long long t = wall_clock64(); meta->pmax[0] = (uint32_t)t_setup; meta->pmin[0] = (uint32_t)t_iter; meta->pad2 = (int32_t)(t - t_mark); }
 #endif
@@ -1546,8 +1659,8 @@ void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
 }
 
 size_t phxk_sssp_lds_bytes(int V, int nl) {
-    (void)V; // the LDS kernel keeps a fixed-size ring of distances: its footprint does not depend on the contig
-    return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + 64;
+    // fixed-size ring of distances + in-edge tile + one plan byte per window of SW_ADV nodes
+    return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + (size_t)(V / SW_ADV + 1) + 64;
 }
 
 // mode 0: global-memory kernel (+ k_path); mode 1/2: LDS kernel with `lds_bytes` of dynamic LDS
