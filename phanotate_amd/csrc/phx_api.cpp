@@ -231,6 +231,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         m.bits_off = words; m.item_off = items;
         words += 12 * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
         off += L;
+        off = (off + 15) & ~(int64_t)15; // 16-byte aligned rows let the feature kernel store uint4
     }
     c->tot_words = words; c->tot_items = items;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
@@ -338,12 +339,25 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
     phx_rbs_table(t6.data(), t5.data(), t4.data(), t3.data());
-    if (hipMalloc((void **)&c->d_params, sizeof(DParams)) != hipSuccess || hipMalloc((void **)&c->d_t6, 4096 * 4) != hipSuccess ||
-        hipMalloc((void **)&c->d_t5, 1024 * 4) != hipSuccess || hipMalloc((void **)&c->d_t4, 256 * 4) != hipSuccess ||
-        hipMalloc((void **)&c->d_t3, 64 * 4) != hipSuccess) { c->err = "hipMalloc failed"; return fail(PHX_E_NOMEM); }
-    if (hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t6, t6.data(), 4096 * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_t5, t5.data(), 1024 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t4, t4.data(), 256 * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_t3, t3.data(), 64 * 4, hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(PHX_E_HIP); }
+    // compact device tables: every motif starts with ag, ga or gg (codes a0 c1 t2 g3; symbol j at bits 2j)
+    const uint32_t pair_code[3] = {0u | (3u << 2), 3u | (0u << 2), 3u | (3u << 2)};
+    std::vector<uint32_t> c6(768), c5(192), c4(48), c3(12);
+    for (uint32_t q = 0; q < 3; q++) {
+        for (uint32_t r = 0; r < 256; r++) c6[q * 256 + r] = t6[pair_code[q] | (r << 4)];
+        for (uint32_t r = 0; r < 64; r++) c5[q * 64 + r] = t5[pair_code[q] | (r << 4)];
+        for (uint32_t r = 0; r < 16; r++) c4[q * 16 + r] = t4[pair_code[q] | (r << 4)];
+        for (uint32_t r = 0; r < 4; r++) c3[q * 4 + r] = t3[pair_code[q] | (r << 4)];
+    }
+    for (uint32_t code = 0; code < 4096; code++) { // the compaction must not drop a scoring k-mer
+        const uint32_t p2 = code & 15u;
+        if (p2 != pair_code[0] && p2 != pair_code[1] && p2 != pair_code[2] && (t6[code] | t5[code & 1023] | t4[code & 255] | t3[code & 63])) { c->err = "rbs table compaction"; return fail(PHX_E_STATE); }
+    }
+    if (hipMalloc((void **)&c->d_params, sizeof(DParams)) != hipSuccess || hipMalloc((void **)&c->d_t6, 768 * 4) != hipSuccess ||
+        hipMalloc((void **)&c->d_t5, 192 * 4) != hipSuccess || hipMalloc((void **)&c->d_t4, 48 * 4) != hipSuccess ||
+        hipMalloc((void **)&c->d_t3, 12 * 4) != hipSuccess) { c->err = "hipMalloc failed"; return fail(PHX_E_NOMEM); }
+    if (hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t6, c6.data(), 768 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_t5, c5.data(), 192 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t4, c4.data(), 48 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->d_t3, c3.data(), 12 * 4, hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(PHX_E_HIP); }
     *out = c;
     return PHX_OK;
 }
@@ -503,7 +517,13 @@ int phx_run(phx_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
     }
     fill_batch(c, &b);
-    { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+    {
+        int maxv = 0;
+        for (const DMeta &m : c->meta) maxv = std::max(maxv, m.n_node);
+        b.defer_overlap = maxv < (1 << 21) ? 1 : 0;
+        StageTimer t(c, ST_EDGE_FILL);
+        phxk_edges_fill(&b, e, s);
+    }
     {
         // one launch per (limb class, memory mode) that occurs in the batch; the launches are independent
         // (disjoint contigs), so all but the first go to side streams and overlap

@@ -142,6 +142,7 @@ struct DBatch {
     uint32_t *esrc;
     double *ew;
     const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge
+    int32_t defer_overlap; // 1: k_edges<true> records overlap edges, k_edge_weights evaluates them (needs node ids < 2^21)
     // output
     int32_t *path;
     DGene *genes;
@@ -160,7 +161,7 @@ void phxk_train(const DBatch *b, void *stream);
 void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
-void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 #ifdef __cplusplus

@@ -122,215 +122,268 @@ __device__ __forceinline__ uint32_t base_code(uint32_t ch, bool &bad) {
 }
 __device__ __forceinline__ int off_class(int o) { return o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)); }
 
-// packed per-class scores of the k-mers that start at s[0] (k = 3..min(6,vmax)), given the 6 symbols
+// packed per-class scores of the k-mers that start at s[0] (k = 3..min(6,v)), given the 6 symbols.
+// Every motif of score_rbs starts with ag, ga or gg, so the tables are stored compactly: [pair][remaining symbols]
+// (768 + 192 + 48 + 12 words instead of 4096 + 1024 + 256 + 64).  Codes: a0 c1 t2 g3, symbol j at bits 2j.
 __device__ __forceinline__ uint32_t kmer_lookup(const uint32_t *t6, const uint32_t *t5, const uint32_t *t4, const uint32_t *t3,
                                                 uint32_t code, int v) {
-    if (v >= 6) return t6[code & 4095u];
-    if (v == 5) return t5[code & 1023u];
-    if (v == 4) return t4[code & 255u];
-    if (v == 3) return t3[code & 63u];
-    return 0u;
+    // pair index + 1 for (s0 | s1<<2): ag = 0|3<<2 = 12 -> 1, ga = 3|0 = 3 -> 2, gg = 15 -> 3, else 0
+    const uint32_t pi = ((1u << 24) | (2u << 6) | (3u << 30)) >> (2 * (code & 15u)) & 3u;
+    if (pi == 0 || v < 3) return 0u;
+    const uint32_t r = (code >> 4) & 255u, q = pi - 1;
+    if (v >= 6) return t6[q * 256 + r];
+    if (v == 5) return t5[q * 64 + (r & 63u)];
+    if (v == 4) return t4[q * 16 + (r & 15u)];
+    return t3[q * 4 + (r & 3u)];
 }
 
+#define FPT (PHX_TILE / PHX_FEAT_THREADS) // tile positions per thread in the output stage (consecutive)
+#define FIT 9 // window indices per thread in the scan stages (consecutive; a multiple of 3, FIT * threads >= FW)
+static_assert(FIT % 3 == 0 && FIT * PHX_FEAT_THREADS >= PHX_TILE + 2 * PHX_HALO, "FIT");
+
 __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const DTile *__restrict__ tiles, int n_tiles) {
-    __shared__ uint8_t s_code[FW];
+    __shared__ uint8_t s_code[FW + 8];
     __shared__ uint16_t s_pref[FW];
-    __shared__ uint8_t s_W[FW];
-    __shared__ uint8_t s_cls[PHX_TILE];
+    __shared__ uint8_t s_W[FW + 8];
     __shared__ uint32_t s_AF[FW], s_AR[FW];
-    __shared__ uint32_t s_t6[4096], s_t5[1024], s_t4[256], s_t3[64];
+    __shared__ uint32_t s_t6[768], s_t5[192], s_t4[48], s_t3[12];
+    __shared__ __align__(16) uint8_t o_cls[PHX_TILE], o_gcc[PHX_TILE], o_cnt[PHX_TILE];
+    __shared__ __align__(16) uint16_t o_rbs[PHX_TILE];
     __shared__ uint32_t s_hist[28];
     __shared__ uint32_t s_scan[PHX_FEAT_THREADS / 64 + 1];
     __shared__ uint32_t s_gc, s_bad;
 
     const int tid = threadIdx.x;
     // the motif tables are loaded once per workgroup; the workgroup then walks over tiles (grid-stride)
-    for (int i = tid; i < 4096; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
-    for (int i = tid; i < 1024; i += PHX_FEAT_THREADS) s_t5[i] = b.rbs_t5[i];
-    if (tid < 256) s_t4[tid] = b.rbs_t4[tid];
-    if (tid < 64) s_t3[tid] = b.rbs_t3[tid];
-    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-    const DTile tile = tiles[ti];
-    DMeta *meta = &b.meta[tile.contig];
-    const int L = meta->L;
-    const int64_t off = meta->off;
-    const int p0 = tile.p0;
-    const uint8_t *__restrict__ ascii = b.ascii + off;
-    __syncthreads(); // the previous tile's LDS is no longer read
-    if (tid < 28) s_hist[tid] = 0;
-    if (tid == 0) { s_gc = 0; s_bad = 0; }
-
-    // 1. stage the tile (+halo) as base codes
-    bool bad = false;
-    uint32_t mygc = 0;
-    for (int idx = tid; idx < FW; idx += PHX_FEAT_THREADS) {
-        int p = p0 - PHX_HALO + idx;
-        uint32_t c;
-        if (p < 0 || p >= L) c = 8u | 4u;
-        else {
-            c = base_code(ascii[p], bad);
-            if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE) mygc += c & 1u;
-        }
-        s_code[idx] = (uint8_t)c;
-    }
-    __syncthreads();
-
-    // 2. per-residue exclusive GC prefix over the window (three interleaved sums, packed 3 x 10 bit)
-    {
-        const int i0 = tid * 9;
-        uint32_t loc = 0;
-        for (int k = 0; k < 9; k++) {
-            int idx = i0 + k;
-            if (idx < FW) loc += (uint32_t)(s_code[idx] & 1u) << (10 * (k % 3));
-        }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan<PHX_FEAT_THREADS>(loc, s_scan, &tot);
-        uint32_t run[3] = {ex & 1023u, (ex >> 10) & 1023u, (ex >> 20) & 1023u};
-        for (int k = 0; k < 9; k++) {
-            int idx = i0 + k;
-            if (idx < FW) {
-                s_pref[idx] = (uint16_t)run[k % 3];
-                run[k % 3] += s_code[idx] & 1u;
-            }
-        }
-    }
-    __syncthreads();
-    // 3. W(q) = GC count over q+3m, m in [-19,20] (gc_frame_plot.py:44-59); k-mer class scores
-    for (int idx = tid; idx < FW; idx += PHX_FEAT_THREADS) {
-        if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE + 2)
-            s_W[idx] = (uint8_t)(s_pref[idx + 60] + (s_code[idx + 60] & 1u) - s_pref[idx - 57]);
-        uint32_t af = 0, ar = 0;
-        if (idx >= 5) { // leftward 6-mer: s[k] = dna[y-k]
-            uint32_t code = 0; int v = 0; bool ok = true;
-            for (int k = 0; k < 6; k++) {
-                uint32_t c = s_code[idx - k];
-                ok = ok && !(c & 4u);
-                if (ok) v++;
-                code |= (c & 3u) << (2 * k);
-            }
-            af = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
-        }
-        if (idx + 5 < FW) { // rightward complemented 6-mer: s[k] = comp(dna[y+k])
-            uint32_t code = 0; int v = 0; bool ok = true;
-            for (int k = 0; k < 6; k++) {
-                uint32_t c = s_code[idx + k];
-                ok = ok && !(c & 4u);
-                if (ok) v++;
-                code |= ((c & 3u) ^ 2u) << (2 * k);
-            }
-            ar = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
-        }
-        s_AF[idx] = af;
-        s_AR[idx] = ar;
-    }
-    __syncthreads();
-
-    // 4. per-position outputs (bin 0 of the RBS histogram is by far the most frequent: counted per thread)
+    for (int i = tid; i < 768; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
+    if (tid < 192) s_t5[tid] = b.rbs_t5[tid];
+    if (tid < 48) s_t4[tid] = b.rbs_t4[tid];
+    if (tid < 12) s_t3[tid] = b.rbs_t3[tid];
     const DParams *P = b.params;
-    uint32_t nz0 = 0;
-    for (int j = tid; j < PHX_TILE; j += PHX_FEAT_THREADS) {
-        const int p = p0 + j;
-        uint32_t cls = 0;
-        if (p < L) {
-            const int idx = PHX_HALO + j;
-            const uint32_t c0 = s_code[idx], c1 = s_code[idx + 1], c2 = s_code[idx + 2];
-            uint32_t atg = 0, gcc = 0, cnt = 0;
-            if (p <= L - 3) {
-                if (!((c0 | c1 | c2) & 4u)) {
-                    uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
-                    cls = P->cls_tab[ci];
-                    atg = P->atg_tab[ci];
-                }
-                int w0 = s_W[idx], w1 = s_W[idx + 1], w2 = s_W[idx + 2];
-                uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
-                uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
-                gcc = f | (r << 4);
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        const DTile tile = tiles[ti];
+        DMeta *meta = &b.meta[tile.contig];
+        const int L = meta->L;
+        const int64_t off = meta->off;
+        const int p0 = tile.p0;
+        const uint8_t *__restrict__ ascii = b.ascii + off;
+        __syncthreads(); // the previous tile's LDS is no longer read
+        if (tid < 28) s_hist[tid] = 0;
+        if (tid == 0) { s_gc = 0; s_bad = 0; }
+
+        // 1. stage the tile (+halo) as base codes
+        bool bad = false;
+        uint32_t mygc = 0;
+        for (int idx = tid; idx < FW + 8; idx += PHX_FEAT_THREADS) {
+            const int p = p0 - PHX_HALO + idx;
+            uint32_t c;
+            if (idx >= FW || p < 0 || p >= L) c = 8u | 4u;
+            else {
+                c = base_code(ascii[p], bad);
+                if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE) mygc += c & 1u;
             }
-            { // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7
-                const uint32_t cc[3] = {c0, c1, c2};
-                for (int k = 0; k < 3; k++)
-                    if (!(cc[k] & 4u)) {
-                        uint32_t x = cc[k] & 3u; // a0 c1 t2 g3
-                        cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
+            s_code[idx] = (uint8_t)c;
+        }
+        __syncthreads();
+
+        // 2. per-residue exclusive GC prefix over the window (three interleaved sums, packed 3 x 10 bit);
+        //    every thread owns FIT consecutive window indices (FIT is a multiple of 3)
+        const int i0 = tid * FIT;
+        {
+            uint32_t loc = 0;
+#pragma unroll
+            for (int k = 0; k < FIT; k++) {
+                const int idx = i0 + k;
+                if (idx < FW) loc += (uint32_t)(s_code[idx] & 1u) << (10 * (k % 3));
+            }
+            uint32_t tot;
+            uint32_t ex = block_excl_scan<PHX_FEAT_THREADS>(loc, s_scan, &tot);
+            uint32_t run[3] = {ex & 1023u, (ex >> 10) & 1023u, (ex >> 20) & 1023u};
+#pragma unroll
+            for (int k = 0; k < FIT; k++) {
+                const int idx = i0 + k;
+                if (idx < FW) {
+                    s_pref[idx] = (uint16_t)run[k % 3];
+                    run[k % 3] += s_code[idx] & 1u;
+                }
+            }
+        }
+        // 3a. k-mer class scores with rolling 6-mer codes over the thread's consecutive indices:
+        //     leftward 6-mer s[k] = dna[y-k] (forward windows) scanning up, rightward complemented 6-mer
+        //     s[k] = comp(dna[y+k]) (reverse windows) scanning down
+        {
+            uint32_t code = 0; int v = 0;
+#pragma unroll
+            for (int k = 5; k >= 1; k--) {
+                const int idx = i0 - k;
+                const uint32_t c = idx >= 0 ? s_code[idx] : 12u;
+                code = ((code << 2) | (c & 3u)) & 4095u;
+                v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+            }
+#pragma unroll
+            for (int k = 0; k < FIT; k++) {
+                const int idx = i0 + k;
+                if (idx < FW) {
+                    const uint32_t c = s_code[idx];
+                    code = ((code << 2) | (c & 3u)) & 4095u;
+                    v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+                    s_AF[idx] = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
+                }
+            }
+            code = 0; v = 0;
+            const int ie = i0 + FIT - 1; // last index of this thread
+#pragma unroll
+            for (int k = 5; k >= 1; k--) {
+                const int idx = ie + k;
+                const uint32_t c = idx < FW + 8 ? s_code[idx] : 12u;
+                code = ((code << 2) | ((c & 3u) ^ 2u)) & 4095u;
+                v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+            }
+#pragma unroll
+            for (int k = FIT - 1; k >= 0; k--) {
+                const int idx = i0 + k;
+                if (idx < FW) {
+                    const uint32_t c = s_code[idx];
+                    code = ((code << 2) | ((c & 3u) ^ 2u)) & 4095u;
+                    v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+                    s_AR[idx] = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
+                }
+            }
+        }
+        __syncthreads();
+        // 3b. W(q) = GC count over q+3m, m in [-19,20] (gc_frame_plot.py:44-59)
+        for (int idx = PHX_HALO + tid; idx < PHX_HALO + PHX_TILE + 8; idx += PHX_FEAT_THREADS)
+            s_W[idx] = (uint8_t)(idx + 60 < FW ? s_pref[idx + 60] + (s_code[idx + 60] & 1u) - s_pref[idx - 57] : 0);
+        __syncthreads();
+
+        // 4. per-position outputs; every thread owns FPT consecutive positions, the k-mer scores it needs sit in registers
+        uint32_t nz0 = 0;
+        {
+            const int j0 = tid * FPT;
+            const int x0 = PHX_HALO + j0;
+            uint32_t af[FPT + 12], ar[FPT + 12]; // af[m] = AF[x0 - 15 + m], ar[m] = AR[x0 + 3 + m]
+#pragma unroll
+            for (int m = 0; m < FPT + 12; m++) { af[m] = s_AF[x0 - 15 + m]; ar[m] = s_AR[x0 + 3 + m]; }
+            uint32_t cd[FPT + 2], wv[FPT + 2];
+#pragma unroll
+            for (int m = 0; m < FPT + 2; m++) { cd[m] = s_code[x0 + m]; wv[m] = s_W[x0 + m]; }
+#pragma unroll
+            for (int j = 0; j < FPT; j++) {
+                const int p = p0 + j0 + j;
+                uint32_t cls = 0, atg = 0, gcc = 0, cnt = 0, bf = 0, br = 0;
+                if (p < L) {
+                    const uint32_t c0 = cd[j], c1 = cd[j + 1], c2 = cd[j + 2];
+                    if (p <= L - 3) {
+                        if (!((c0 | c1 | c2) & 4u)) {
+                            const uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
+                            cls = P->cls_tab[ci];
+                            atg = P->atg_tab[ci];
+                        }
+                        const int w0 = (int)wv[j], w1 = (int)wv[j + 1], w2 = (int)wv[j + 2];
+                        const uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
+                        const uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
+                        gcc = f | (r << 4);
                     }
+                    // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7 (codes a0 c1 t2 g3)
+                    const uint32_t cc[3] = {c0, c1, c2};
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        if (!(cc[k] & 4u)) {
+                            const uint32_t x = cc[k] & 3u;
+                            cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
+                        }
+                    // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21]);
+                    // offsets 3-4 use class byte 0, 5-10 byte 1, 11-12 byte 2, 13-15 byte 3
+#pragma unroll
+                    for (int o = 3; o <= 15; o++) {
+                        const int sh = 8 * (o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)));
+                        const uint32_t sf = (af[15 + j - o] >> sh) & 0xffu, sr = (ar[j + o - 3] >> sh) & 0xffu;
+                        bf = sf > bf ? sf : bf;
+                        br = sr > br ? sr : br;
+                    }
+                    if (p >= 20) { // background: full-length forward window i = p-20 (functions.py:168)
+                        if (bf) atomicAdd(&s_hist[bf], 1u); else nz0++;
+                    } else bf = 0;
+                    if (br) atomicAdd(&s_hist[br], 1u); else nz0++; // background: reverse-complemented window i = p (functions.py:169)
+                }
+                o_cls[j0 + j] = (uint8_t)cls;
+                o_gcc[j0 + j] = (uint8_t)gcc;
+                o_cnt[j0 + j] = (uint8_t)cnt;
+                o_rbs[j0 + j] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
             }
-            // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21])
-            uint32_t bf = 0, br = 0;
-            if (p >= 20) {
+        }
+        // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
+        // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
+        if (L - 1 >= p0 && L - 1 < p0 + PHX_TILE) {
+            const int nt = L < 20 ? L : 20;
+            if (tid < nt) {
+                const int len = tid + 1;
+                const int ie = PHX_HALO + (L - 1 - p0);
+                uint32_t best = 0;
                 for (int o = 3; o <= 15; o++) {
-                    uint32_t sc = (s_AF[idx - o] >> (8 * off_class(o))) & 0xffu;
-                    bf = sc > bf ? sc : bf;
+                    int vmax = len - o;
+                    if (vmax < 3) break;
+                    if (vmax > 6) vmax = 6;
+                    uint32_t code = 0; int v = 0; bool ok = true;
+                    for (int k = 0; k < vmax; k++) {
+                        uint32_t c = s_code[ie - o - k];
+                        ok = ok && !(c & 4u);
+                        if (ok) v++;
+                        code |= (c & 3u) << (2 * k);
+                    }
+                    uint32_t sc = (kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v) >> (8 * off_class(o))) & 0xffu;
+                    best = sc > best ? sc : best;
                 }
-                if (bf) atomicAdd(&s_hist[bf], 1u); // background: full-length window i = p-20 (functions.py:168)
-                else nz0++;
-            }
-            for (int o = 3; o <= 15; o++) {
-                uint32_t sc = (s_AR[idx + o] >> (8 * off_class(o))) & 0xffu;
-                br = sc > br ? sc : br;
-            }
-            if (br) atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
-            else nz0++;
-            b.cls[off + p] = (uint8_t)cls;
-            b.gcc[off + p] = (uint8_t)gcc;
-            b.cnt[off + p] = (uint8_t)cnt;
-            b.rbs[off + p] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
-        }
-        s_cls[j] = (uint8_t)(p <= L - 3 ? cls : 0u);
-    }
-    __syncthreads();
-    // 5. start/stop codon bitmaps by wavefront ballot: lane <-> codon, one 64-bit word per (class, frame, 64 codons).
-    //    p0 is a multiple of 1536 = 3*512, so codon f+3k of this tile is bit (k & 63) of word p0/192 + k/64.
-    {
-        const int lane = tid & 63, wv = tid >> 6;
-        uint64_t *bits = b.bits + meta->bits_off;
-        const int nw = meta->nw;
-        const int wbase = p0 / 192;
-        for (int pair = wv; pair < 24; pair += PHX_FEAT_THREADS / 64) {
-            const int f = pair >> 3, wi = pair & 7;
-            const uint32_t c = s_cls[f + 3 * (64 * wi + lane)] & 7u;
-            const uint64_t m1 = __ballot(c == CLS_FS), m2 = __ballot(c == CLS_RS), m3 = __ballot(c == CLS_FT), m4 = __ballot(c == CLS_RT);
-            if (lane == 0) {
-                bits[(size_t)(0 * 3 + f) * nw + wbase + wi] = m1;
-                bits[(size_t)(1 * 3 + f) * nw + wbase + wi] = m2;
-                bits[(size_t)(2 * 3 + f) * nw + wbase + wi] = m3;
-                bits[(size_t)(3 * 3 + f) * nw + wbase + wi] = m4;
+                atomicAdd(&s_hist[best], 1u);
             }
         }
-    }
-    // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
-    // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
-    if (L - 1 >= p0 && L - 1 < p0 + PHX_TILE) {
-        const int nt = L < 20 ? L : 20;
-        if (tid < nt) {
-            const int len = tid + 1;
-            const int ie = PHX_HALO + (L - 1 - p0);
-            uint32_t best = 0;
-            for (int o = 3; o <= 15; o++) {
-                int vmax = len - o;
-                if (vmax < 3) break;
-                if (vmax > 6) vmax = 6;
-                uint32_t code = 0; int v = 0; bool ok = true;
-                for (int k = 0; k < vmax; k++) {
-                    uint32_t c = s_code[ie - o - k];
-                    ok = ok && !(c & 4u);
-                    if (ok) v++;
-                    code |= (c & 3u) << (2 * k);
+        if (mygc) atomicAdd(&s_gc, mygc);
+        if (nz0) atomicAdd(&s_hist[0], nz0);
+        if (bad) s_bad = 1;
+        __syncthreads();
+        // 5. write-out.  Full tiles with 16-byte aligned rows go out as uint4 (coalesced 1 KiB per wave instruction).
+        const bool vec = p0 + PHX_TILE <= L && ((off + p0) & 15) == 0;
+        if (vec) {
+            uint4 *gc4 = (uint4 *)(b.cls + off + p0), *gg4 = (uint4 *)(b.gcc + off + p0), *gn4 = (uint4 *)(b.cnt + off + p0), *gr4 = (uint4 *)(b.rbs + off + p0);
+            for (int i = tid; i < PHX_TILE / 16; i += PHX_FEAT_THREADS) {
+                gc4[i] = ((const uint4 *)o_cls)[i];
+                gg4[i] = ((const uint4 *)o_gcc)[i];
+                gn4[i] = ((const uint4 *)o_cnt)[i];
+            }
+            for (int i = tid; i < PHX_TILE / 8; i += PHX_FEAT_THREADS) gr4[i] = ((const uint4 *)o_rbs)[i];
+        } else {
+            for (int j = tid; j < PHX_TILE && p0 + j < L; j += PHX_FEAT_THREADS) {
+                b.cls[off + p0 + j] = o_cls[j];
+                b.gcc[off + p0 + j] = o_gcc[j];
+                b.cnt[off + p0 + j] = o_cnt[j];
+                b.rbs[off + p0 + j] = o_rbs[j];
+            }
+        }
+        // start/stop codon bitmaps by wavefront ballot: lane <-> codon, one 64-bit word per (class, frame, 64 codons).
+        // p0 is a multiple of 1536 = 3*512, so codon f+3k of this tile is bit (k & 63) of word p0/192 + k/64.
+        {
+            const int lane = tid & 63, wv = tid >> 6;
+            uint64_t *bits = b.bits + meta->bits_off;
+            const int nw = meta->nw;
+            const int wbase = p0 / 192;
+            for (int pair = wv; pair < 24; pair += PHX_FEAT_THREADS / 64) {
+                const int f = pair >> 3, wi = pair & 7;
+                const int j = f + 3 * (64 * wi + lane);
+                const uint32_t c = (p0 + j <= L - 3) ? (o_cls[j] & 7u) : 0u;
+                const uint64_t m1 = __ballot(c == CLS_FS), m2 = __ballot(c == CLS_RS), m3 = __ballot(c == CLS_FT), m4 = __ballot(c == CLS_RT);
+                if (lane == 0) {
+                    bits[(size_t)(0 * 3 + f) * nw + wbase + wi] = m1;
+                    bits[(size_t)(1 * 3 + f) * nw + wbase + wi] = m2;
+                    bits[(size_t)(2 * 3 + f) * nw + wbase + wi] = m3;
+                    bits[(size_t)(3 * 3 + f) * nw + wbase + wi] = m4;
                 }
-                uint32_t s = (kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v) >> (8 * off_class(o))) & 0xffu;
-                best = s > best ? s : best;
             }
-            atomicAdd(&s_hist[best], 1u);
         }
-    }
-    if (mygc) atomicAdd(&s_gc, mygc);
-    if (nz0) atomicAdd(&s_hist[0], nz0);
-    if (bad) s_bad = 1;
-    __syncthreads();
-    if (tid < 28 && s_hist[tid]) atomicAdd(&meta->bg[tid], s_hist[tid]);
-    if (tid == 0) {
-        if (s_gc) atomicAdd(&meta->gc, s_gc);
-        if (s_bad) atomicMin(&meta->status, PHX_S_BADLETTER);
-    }
+        if (tid < 28 && s_hist[tid]) atomicAdd(&meta->bg[tid], s_hist[tid]);
+        if (tid == 0) {
+            if (s_gc) atomicAdd(&meta->gc, s_gc);
+            if (s_bad) atomicMin(&meta->status, PHX_S_BADLETTER);
+        }
     } // tiles
 }
 
@@ -843,10 +896,23 @@ struct EdgeSink {
     uint32_t *esrc;
     double *ew;
     int n;
+    bool defer; // overlap weights are finished by k_edge_weights (node ids must fit 21 bits)
 };
 template <bool FILL>
 __device__ __forceinline__ void emit_edge(EdgeSink &s, int src, double w) {
     if (FILL) { s.esrc[s.n] = (uint32_t)src; s.ew[s.n] = w; }
+    s.n++;
+}
+// Overlap edge r -> l: 1/(1-pstop)^length (+20 across strands), functions.py:26-34.  pow() inside the divergent
+// neighbour scan would run for the whole wavefront whenever one lane needs it, so the scan only records
+// (source, length, direction, pstop) and k_edge_weights evaluates the power with every lane busy.
+#define EDGE_PENDING 0x80000000u
+template <bool FILL>
+__device__ __forceinline__ void emit_overlap(EdgeSink &s, int src, int length, bool diff, double ps) {
+    if (FILL) {
+        if (s.defer) { s.esrc[s.n] = (uint32_t)src | ((uint32_t)length << 21) | (diff ? 0x40000000u : 0u) | EDGE_PENDING; s.ew[s.n] = ps; }
+        else { s.esrc[s.n] = (uint32_t)src; s.ew[s.n] = score_overlap(length, diff, ps); }
+    }
     s.n++;
 }
 
@@ -880,10 +946,25 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
         return diff ? s_gap[length + 2] + 20.0 : s_gap[length + 2];
     };
 
+    // the node attributes of this block's 256 nodes and of 128 neighbours on either side are staged in LDS
+    // (a +-500 bp window holds ~30-60 nodes); scans that run past the staged range fall back to global memory
+    __shared__ int32_t s_pos[NT + 256], s_info[NT + 256], s_oth[NT + 256];
+    __shared__ double s_o[NT + 256];
     for (int base = (int)blockIdx.y * NT; base < V; base += (int)gridDim.y * NT) {
+        const int lo = base - 128 > 0 ? base - 128 : 0;
+        const int hi = base + NT + 128 < ncds ? base + NT + 128 : ncds;
+        const int nst = hi - lo;
+        __syncthreads();
+        for (int k = threadIdx.x; k < nst; k += NT) { s_pos[k] = npos[lo + k]; s_info[k] = ninfo[lo + k]; s_oth[k] = nother[lo + k]; s_o[k] = no[lo + k]; }
+        __syncthreads();
+        auto POS = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_pos[k] : npos[u]; };
+        auto INFO = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_info[k] : ninfo[u]; };
+        auto OTH = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_oth[k] : nother[u]; };
+        auto NO = [&](int u) -> double { const int k = u - lo; return (k >= 0 && k < nst) ? s_o[k] : no[u]; };
         const int v = base + (int)threadIdx.x;
         EdgeSink sink;
         sink.n = 0;
+        sink.defer = b.defer_overlap != 0;
         if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
         if (v < V && v != SRC) {
             if (v == TGT) {
@@ -893,7 +974,7 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                     if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, gap(L - npos[u], false));
                 }
             } else {
-                const int t = NTYPE(ninfo[v]), f = NFRAME(ninfo[v]), pos = npos[v];
+                const int t = NTYPE(INFO(v)), f = NFRAME(INFO(v)), pos = POS(v);
                 const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
                 if (!open) {
                     // ORF edges, functions.py:311-318
@@ -905,15 +986,16 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                         emit_edge<FILL>(sink, grp[r->grp].node, r->weight);
                     }
                 } else {
-                    const int my_other = nother[v];
-                    const double my_o = no[v];
+                    const int my_other = OTH(v);
+                    const double my_o = NO(v);
                     if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
                     // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
                     for (int u = v - 1; u >= 0; u--) {
-                        const int d = pos - npos[u];
+                        const int d = pos - POS(u);
                         if (d >= 500) break;
                         if (d <= 0) continue;
-                        const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
+                        const int iu = INFO(u);
+                        const int lt = NTYPE(iu), lf = NFRAME(iu);
                         if (t == 0) { // v = forward start
                             if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
                             else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, gap(d - 3, true));
@@ -924,24 +1006,25 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
                     }
                     // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
                     for (int u = v + 1; u < ncds; u++) {
-                        const int r = npos[u];
+                        const int r = POS(u);
                         const int d = r - pos;
                         if (d >= 500) break;
                         if (d <= 0) continue;
-                        const int rt = NTYPE(ninfo[u]), rf = NFRAME(ninfo[u]);
-                        const int r_other = nother[u];
-                        const double ps = (my_o + no[u]) / 2.0; // ave([o1,o2]), functions.py:385
+                        const int iu = INFO(u);
+                        const int rt = NTYPE(iu), rf = NFRAME(iu);
+                        const int r_other = OTH(u);
+                        const double ps = (my_o + NO(u)) / 2.0; // ave([o1,o2]), functions.py:385
                         if (t == 1) { // v = reverse stop (l), lf < 0
                             if (rt == 0 && rf < 0) { // same strand: right is a reverse start
-                                if (f != rf && r < my_other && r_other < pos) emit_edge<FILL>(sink, u, score_overlap(d + 3, false, ps));
+                                if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
                             } else if (rt == 1 && rf > 0) { // right is a forward stop
-                                if (r_other + 3 < pos && r < my_other) emit_edge<FILL>(sink, u, score_overlap(d + 3, true, ps));
+                                if (r_other + 3 < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
                             }
                         } else { // v = forward start (l), lf > 0
                             if (rt == 1 && rf > 0) { // same strand: right is a forward stop
-                                if (f != rf && r < my_other && r_other < pos) emit_edge<FILL>(sink, u, score_overlap(d + 3, false, ps));
+                                if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
                             } else if (rt == 0 && rf < 0) { // right is a reverse start
-                                if (r_other < pos && r < my_other) emit_edge<FILL>(sink, u, score_overlap(d + 3, true, ps));
+                                if (r_other < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
                             }
                         }
                     }
@@ -975,6 +1058,18 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
         if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
     }
     if (parallel) atomicMin(&meta->status, PHX_S_PARALLEL);
+}
+
+// dense pass over the batch's edge arrays: finish the overlap weights recorded by k_edges<true>
+__global__ __launch_bounds__(256) void k_edge_weights(uint32_t *__restrict__ esrc, double *__restrict__ ew, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t sv = esrc[e];
+    if (sv & EDGE_PENDING) {
+        const int length = (int)((sv >> 21) & 511u);
+        esrc[e] = sv & 0x1fffffu;
+        ew[e] = score_overlap(length, (sv & 0x40000000u) != 0, ew[e]);
+    }
 }
 
 // in-degrees -> exclusive offsets (CSR by destination), one workgroup per contig
@@ -1645,7 +1740,11 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream) {
+    hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    if (b->defer_overlap && n_edges > 0)
+        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->esrc, b->ew, n_edges);
+}
 // phx_solve: the relaxation alone, no path/gene emission (the caller walks the parent edges)
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
     dim3 g(b->n_contig), t(NT);
