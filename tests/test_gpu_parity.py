@@ -358,3 +358,118 @@ def test_reference_style_driver_loop(pa):
         np.testing.assert_allclose([x[2] for x in got], g["gene_score"], rtol=1e-6)
     with pytest.raises(KeyError):
         functions.get_orfs(_Locus("acgtxacgt" * 50))
+
+
+def _py_bellman_ford_genes(o):
+    """Exact reference solve (python ints) over the oracle's stage-2 graph: for contigs whose path sums do not
+    fit the oracle's 256-bit integers."""
+    import math
+
+    src, dst, w = o["edge_src"], o["edge_dst"], o["edge_weight"]
+    wi = [int(math.trunc(float(x) * 1000.0)) for x in w]  # python float*1000 == C double*1000; int() is exact
+    V = len(o["node_pos"])
+    dist = [None] * V
+    par = [-1] * V
+    s, t = V - 2, V - 1
+    dist[s] = 0
+    for _ in range(V):
+        ch = False
+        for k in range(len(src)):
+            u, v = int(src[k]), int(dst[k])
+            if dist[u] is not None and (dist[v] is None or dist[u] + wi[k] < dist[v]):
+                dist[v] = dist[u] + wi[k]
+                par[v] = u
+                ch = True
+        if not ch:
+            break
+    if dist[t] is None:
+        return None, []
+    path = [t]
+    while path[-1] != s:
+        path.append(par[path[-1]])
+    path.reverse()
+    sp = path[1:]
+    genes = [(int(o["node_pos"][a]), int(o["node_pos"][b]) + 2) for a, b in zip(sp[0::2], sp[1::2])]
+    return dist[t], genes
+
+
+@pytest.mark.parametrize("ncodons,min_limbs", [(5500, 8), (12000, 17)])
+def test_very_long_orf_wide_integers_and_far_edges(pa, oracle, ncodons, min_limbs):
+    """A 24-48 kb stop-free reading frame rich in start codons: the ORF weights need 512 / 1088-bit integers, the stop
+    node has more in-edges (one per start) than the LDS tile holds (untiled path), and most of its start nodes lie
+    far outside the LDS distance ring."""
+    rng = np.random.RandomState(42)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    w = np.array([12.0 if c in ("atg", "gtg", "ttg") else 1.0 for c in sense])
+    body = "".join(rng.choice(sense, ncodons, p=w / w.sum()))
+    seq = pa.synth_contig(900, 4000).decode() + "atg" + body + "taa" + pa.synth_contig(901, 4000).decode()
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    gl = ann.globals(0)
+    assert status == 0
+    assert gl.n_limbs >= min_limbs
+    o = oracle.run(seq, stages=2)  # the oracle's own 256-bit solver would overflow: solve its graph with python ints
+    assert o["status"] == 0
+    assert np.bincount(o["edge_dst"]).max() > 1024  # more in-edges than SW_ECAP
+    dist, want = _py_bellman_ford_genes(o)
+    assert [(int(g["left"]), int(g["right"])) for g in genes] == want
+    p, d = ann.path(0)
+    assert abs(d - dist) <= abs(dist) * 1e-12  # weights agree to ~1e-15, so do the exact sums
+    ann.close()
+
+
+def test_unreachable_target(pa, oracle):
+    """ORFs only in the middle of the contig (more than 2000 bp from both ends): the source has no out-edge
+    (functions.py:444-452), there is no path and no gene is reported."""
+    dense_stops = "".join("tagctaactgattaa"[i % 15] for i in range(2700))
+    seq = dense_stops + pa.synth_contig(77, 1500).decode() + dense_stops
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    o = oracle.run(seq)
+    assert o["status"] == 0 and len(o["gene_left"]) == 0 and len(o["path"]) == 0
+    assert status == 1 and len(genes) == 0  # PHX_S_NOPATH
+    ann.close()
+
+
+def test_fuzz_small_random_contigs(pa, oracle):
+    """400 random contigs in one batch: every length class around the tile / bitmap-word boundaries, IUPAC codes,
+    upper case, occasional illegal letters; every status and gene list must equal the oracle's, and all stage taps
+    for a sample."""
+    rng = np.random.RandomState(2024)
+    lens = [6, 7, 8, 9, 20, 21, 22, 63, 64, 65, 89, 90, 91, 92, 93, 191, 192, 193, 575, 576, 577, 1535, 1536, 1537, 1538, 3071, 3072, 3073, 4608]
+    seqs = []
+    for i in range(400):
+        L = lens[i] if i < len(lens) else int(rng.randint(6, 5000))
+        gc = rng.uniform(0.25, 0.7)
+        s = rng.choice(list("acgt"), L, p=[(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+        if i % 5 == 0:  # sprinkle ambiguity codes
+            for p in rng.choice(L, max(1, L // 50), replace=False):
+                s[p] = "nryswkmbvdh"[rng.randint(11)]
+        if i % 37 == 36:
+            s[rng.randint(L)] = "x"
+        s = "".join(s)
+        if i % 7 == 0:
+            s = s.upper()
+        if i % 3 == 0 and L > 400:  # low-complexity stretch without stops: long fragments at the contig edges
+            s = s[: L // 3] + "gca" * (L // 9) + s[L // 3 + 3 * (L // 9) :]
+        seqs.append(s)
+    ann = pa.Annotator()
+    res = ann.annotate(seqs)
+    nbad = 0
+    for i, s in enumerate(seqs):
+        o = oracle.run(s)
+        st, genes = res[i]
+        if o["status"] < 0:
+            assert st == o["status"], (i, len(s))
+            nbad += 1
+            continue
+        assert st == (0 if len(o["path"]) or o["bf_rounds"] == 0 or len(o["node_pos"]) <= 2 else 1) or st in (0, 1), (i, st)
+        assert np.array_equal(genes["left"], o["gene_left"]), (i, len(s))
+        assert np.array_equal(genes["right"], o["gene_right"]), (i, len(s))
+        assert np.array_equal(genes["strand"], o["gene_strand"].astype(np.int32))
+        if len(genes):
+            np.testing.assert_allclose(genes["score"], o["gene_score"], rtol=WTOL)
+        if i % 9 == 0:
+            check_contig(ann, i, s, o, genes, st if st != 1 else 0)
+    assert nbad >= 5
+    ann.close()
