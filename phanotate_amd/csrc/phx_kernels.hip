@@ -564,10 +564,15 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
     o.linkF = b.linkF + off;
     o.linkR = b.linkR + off;
     const int nitems = 6 * nw;
-    const int per = (nitems + NT - 1) / NT;
-    const int ia = (int)threadIdx.x * per, ib = ia + per < nitems ? ia + per : nitems;
+    // count pass: one workgroup per contig (it needs the block scan); emit pass: the items are spread over
+    // gridDim.y workgroups, every thread takes one item at a time (offsets are already known)
+    const int nthr = EMIT ? NT * (int)gridDim.y : NT;
+    const int gtid = EMIT ? (int)blockIdx.y * NT + (int)threadIdx.x : (int)threadIdx.x;
+    const int per = EMIT ? 1 : (nitems + NT - 1) / NT;
+    const int ia = EMIT ? gtid : (int)threadIdx.x * per, ib = EMIT ? nitems : (ia + per < nitems ? ia + per : nitems);
+    const int istep = EMIT ? nthr : 1;
     uint32_t so = 0, sg = 0;
-    for (int it = ia; it < ib; it++) {
+    for (int it = ia; it < ib; it += istep) {
         const int sf = it / nw, w = it - sf * nw;
         const int s = sf / 3, f = sf - 3 * s;
         const FrameBits F = frame_bits(bits, nw, f, L);
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
         run_orf = meta->n_orf_main; run_grp = meta->n_grp_main;
     }
     // fragments at the right end, functions.py:229-251: frame 1 fwd, frame 1 rev, frame 2 fwd, ...
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         if (!EMIT) { meta->n_orf_main = run_orf; meta->n_grp_main = run_grp; }
         for (int f = 0; f < 3; f++) {
             const FrameBits F = frame_bits(bits, nw, f, L);
@@ -796,43 +801,53 @@ __global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
     int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off, *nother = b.nother + meta->node_off;
     uint32_t *nlink = b.nlink + meta->node_off;
     double *no = b.no + meta->node_off;
-    // A. coverage by the longest ORF of every stop-group (functions.py:321-330)
-    for (int g = tid; g < meta->n_grp; g += NT) {
-        const DGrp G = grp[g];
-        const DOrf *r = &orf[G.orf_begin + G.n - 1];
-        int mi = r->start < r->stop ? r->start : r->stop;
-        int ma = r->start > r->stop ? r->start : r->stop;
-        if (ma > L - 1) ma = L - 1;
-        for (int n = mi; n < ma; n++) cov[n] = 1;
-    }
     if (tid == 0) meta->n_bridge = 0;
     __syncthreads();
-    // B. ordered sweep over positions: node ids, and "previous covered base" for the bridge test
+    // ordered sweep over positions: node ids, and "previous covered base" for the bridge test.
+    //    Every thread owns NPP consecutive positions per round; one sum-scan and one max-scan per NT*NPP positions.
+    constexpr int NPP = 8;
     int run = 0;
     uint32_t lastcov = 0;
-    for (int base = 0; base < L; base += NT) {
-        const int i = base + tid;
-        uint32_t lf = 0, lr = 0, cv = 0;
-        if (i < L) { lf = linkF[i]; lr = linkR[i]; cv = cov[i] ? (uint32_t)i : 0u; }
+    for (int base = 0; base < L; base += NT * NPP) {
+        const int i0 = base + tid * NPP;
+        uint32_t lf[NPP], lr[NPP], cv[NPP];
+        uint32_t cnt = 0, lmax = 0;
+#pragma unroll
+        for (int j = 0; j < NPP; j++) {
+            const int i = i0 + j;
+            lf[j] = i < L ? linkF[i] : 0u;
+            lr[j] = i < L ? linkR[i] : 0u;
+            cv[j] = (i < L && cov[i]) ? (uint32_t)i : 0u;
+            cnt += (lf[j] ? 1u : 0u) + (lr[j] ? 1u : 0u);
+            lmax = cv[j] > lmax ? cv[j] : lmax;
+        }
         uint32_t tot, mtot;
-        uint32_t ex = block_excl_scan<NT>((lf ? 1u : 0u) + (lr ? 1u : 0u), s_scan, &tot);
-        uint32_t pm = block_excl_max<NT>(cv, s_scan, &mtot);
+        const uint32_t ex = block_excl_scan<NT>(cnt, s_scan, &tot);
+        uint32_t pm = block_excl_max<NT>(lmax, s_scan, &mtot);
         if (pm < lastcov) pm = lastcov;
-        if (cv && (int)cv - (int)pm > 500) { // functions.py:334
-            int k = atomicAdd(&meta->n_bridge, 1);
-            if (k < PHX_MAX_BRIDGE) { meta->bridge[k].last = (int)pm; meta->bridge[k].base = (int)cv; }
-        }
         int id = run + (int)ex;
-        if (lf) {
-            npos[id] = i + 1; nlink[id] = lf;
-            ninfo[id] = NINFO(LINK_KIND(lf) == LINK_START ? 0 : 1, i % 3 + 1);
-            if (LINK_KIND(lf) == LINK_START) orf[LINK_IDX(lf)].node = id; else grp[LINK_IDX(lf)].node = id;
-            id++;
-        }
-        if (lr) {
-            npos[id] = i + 1; nlink[id] = lr;
-            ninfo[id] = NINFO(LINK_KIND(lr) == LINK_START ? 0 : 1, -(i % 3 + 1));
-            if (LINK_KIND(lr) == LINK_START) orf[LINK_IDX(lr)].node = id; else grp[LINK_IDX(lr)].node = id;
+#pragma unroll
+        for (int j = 0; j < NPP; j++) {
+            const int i = i0 + j;
+            if (cv[j]) {
+                if ((int)cv[j] - (int)pm > 500) { // functions.py:334
+                    const int k = atomicAdd(&meta->n_bridge, 1);
+                    if (k < PHX_MAX_BRIDGE) { meta->bridge[k].last = (int)pm; meta->bridge[k].base = (int)cv[j]; }
+                }
+                pm = cv[j];
+            }
+            if (lf[j]) {
+                npos[id] = i + 1; nlink[id] = lf[j];
+                ninfo[id] = NINFO(LINK_KIND(lf[j]) == LINK_START ? 0 : 1, i % 3 + 1);
+                if (LINK_KIND(lf[j]) == LINK_START) orf[LINK_IDX(lf[j])].node = id; else grp[LINK_IDX(lf[j])].node = id;
+                id++;
+            }
+            if (lr[j]) {
+                npos[id] = i + 1; nlink[id] = lr[j];
+                ninfo[id] = NINFO(LINK_KIND(lr[j]) == LINK_START ? 0 : 1, -(i % 3 + 1));
+                if (LINK_KIND(lr[j]) == LINK_START) orf[LINK_IDX(lr[j])].node = id; else grp[LINK_IDX(lr[j])].node = id;
+                id++;
+            }
         }
         run += (int)tot;
         if (mtot > lastcov) lastcov = mtot;
@@ -844,9 +859,23 @@ __global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
         if (run + 2 != meta->n_node) meta->status = PHX_E_STATE; // n_node was sized as n_orf + n_grp + 2
         if (meta->n_bridge > PHX_MAX_BRIDGE) meta->status = PHX_S_OVERFLOW;
     }
-    __syncthreads();
-    // C. other_end[pos] (last writer wins, orfs.py:19-30) and the o1/o2 term (functions.py:373-384)
-    for (int v = tid; v < run; v += NT) {
+}
+
+// other_end[pos] (last writer wins, orfs.py:19-30) and the o1/o2 term (functions.py:373-384), thread per node
+__global__ __launch_bounds__(NT) void k_node_attr(DBatch b) {
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0 || meta->n_node <= 2) return;
+    const int L = meta->L;
+    const int64_t off = meta->off;
+    const DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    const uint32_t *linkF = b.linkF + off, *linkR = b.linkR + off;
+    const int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
+    int32_t *nother = b.nother + meta->node_off;
+    double *no = b.no + meta->node_off;
+    const double pgap = contig_pstop(meta->gc, L);
+    const int run = meta->n_node - 2;
+    for (int v = (int)blockIdx.y * NT + (int)threadIdx.x; v < run; v += (int)gridDim.y * NT) {
         const int q = npos[v] - 1;
         const int fr = NFRAME(ninfo[v]);
         const uint32_t lmine = fr > 0 ? linkF[q] : linkR[q];
@@ -873,6 +902,25 @@ __global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
         }
         nother[v] = oe;
         no[v] = o;
+    }
+}
+
+// coverage by the longest ORF of every stop-group (functions.py:321-330), 16 lanes per group
+__global__ __launch_bounds__(NT) void k_node_cov(DBatch b) {
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0) return;
+    const int L = meta->L;
+    const DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    uint8_t *cov = b.cov + meta->off;
+    const int sub = threadIdx.x & 15;
+    for (int g = (int)blockIdx.y * (NT / 16) + ((int)threadIdx.x >> 4); g < meta->n_grp; g += (int)gridDim.y * (NT / 16)) {
+        const DGrp G = grp[g];
+        const DOrf *r = &orf[G.orf_begin + G.n - 1];
+        int mi = r->start < r->stop ? r->start : r->stop;
+        int ma = r->start > r->stop ? r->start : r->stop;
+        if (ma > L - 1) ma = L - 1;
+        for (int n = mi + sub; n < ma; n += 16) cov[n] = 1;
     }
 }
 
@@ -1731,11 +1779,15 @@ void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *strea
     if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
 }
 void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, 6), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_train(const DBatch *, void *) {}
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_nodes(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_nodes, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_nodes(const DBatch *b, void *stream) {
+    hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_nodes, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+}
 void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
