@@ -29,6 +29,27 @@ def algorithmic_bytes(sz):
     return sz["L"] / 4.0 + 4.0 * sz["L"] + 64.0 * sz["n_orf"] + 32.0 * sz["n_edge"] + 64.0 * sz["n_node"]
 
 
+STAGE_KERNEL = {"sssp": "k_sssp_lds<2>", "features": "k_features", "edges_fill": "k_edges<true>", "edges_count": "k_edges<false>",
+                "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true>", "orf_count": "k_orf<false>", "nodes": "k_nodes", "score": "k_score"}
+
+
+def pmc_traffic(stage, contigs, length):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC run (profiles/traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by tools/pmc_summary.py).
+    Only meaningful for the workload it was collected on."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if contigs != 1000 or length != 50000 or stage not in STAGE_KERNEL or not os.path.exists(path):
+        return None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    for k, v in d.items():
+        if STAGE_KERNEL[stage] in k and "hbm_bytes" in v:
+            return int(v["hbm_bytes"])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,7 +157,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": pmc_traffic(dom, C_, L_),
                 "algorithmic_bytes_per_launch": int(balgo),
                 "avg_launch_ms": round(dom_ms, 4),
             },
