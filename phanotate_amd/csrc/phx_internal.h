@@ -44,8 +44,8 @@ struct DParams { // device copy of phx_params + derived tables
     int32_t minlen;
     int32_t n_start;
     double start_w[PHX_MAX_CODONS];
-    uint8_t cls_tab[64];  // codon code (c0 | c1<<2 | c2<<4) -> cls byte
-    uint8_t atg_tab[64];  // bit0: codon == 'atg', bit1: codon == 'cat'
+    uint8_t cls_tab[72];  // codon code (c0 | c1<<2 | c2<<4) -> cls byte; entry 64 = no codon (0)
+    uint8_t atg_tab[72];  // bit0: codon == 'atg', bit1: codon == 'cat'; entry 64 = 0
 };
 
 struct DOrf {

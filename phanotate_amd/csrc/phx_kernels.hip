@@ -122,31 +122,92 @@ __device__ __forceinline__ uint32_t base_code(uint32_t ch, bool &bad) {
 }
 __device__ __forceinline__ int off_class(int o) { return o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)); }
 
-// packed per-class scores of the k-mers that start at s[0] (k = 3..min(6,v)), given the 6 symbols.
-// Every motif of score_rbs starts with ag, ga or gg, so the tables are stored compactly: [pair][remaining symbols]
-// (768 + 192 + 48 + 12 words instead of 4096 + 1024 + 256 + 64).  Codes: a0 c1 t2 g3, symbol j at bits 2j.
-__device__ __forceinline__ uint32_t kmer_lookup(const uint32_t *t6, const uint32_t *t5, const uint32_t *t4, const uint32_t *t3,
-                                                uint32_t code, int v) {
+// Packed per-class scores of the k-mers that start at s[0] (k = 3..min(6,v)), given the 6 symbols.
+// Every motif of score_rbs starts with ag, ga or gg, so the table is stored compactly: for every usable prefix
+// length v = 6,5,4,3 a block [pair][remaining symbols] (768 + 192 + 48 + 12 words) and one trailing zero word for
+// "no motif can match".  Codes: a0 c1 t2 g3, symbol j at bits 2j.  Branch-free: one LDS read.
+#define RBS_TAB_WORDS 1021
+__device__ __forceinline__ uint32_t kmer_lookup(const uint32_t *tab, uint32_t code, int v) {
     // pair index + 1 for (s0 | s1<<2): ag = 0|3<<2 = 12 -> 1, ga = 3|0 = 3 -> 2, gg = 15 -> 3, else 0
-    const uint32_t pi = ((1u << 24) | (2u << 6) | (3u << 30)) >> (2 * (code & 15u)) & 3u;
-    if (pi == 0 || v < 3) return 0u;
-    const uint32_t r = (code >> 4) & 255u, q = pi - 1;
-    if (v >= 6) return t6[q * 256 + r];
-    if (v == 5) return t5[q * 64 + (r & 63u)];
-    if (v == 4) return t4[q * 16 + (r & 15u)];
-    return t3[q * 4 + (r & 3u)];
+    const uint32_t pi = (((1u << 24) | (2u << 6) | (3u << 30)) >> (2 * (code & 15u))) & 3u;
+    const int vv = v > 6 ? 6 : (v < 2 ? 2 : v);
+    const uint32_t sh = 2u * (uint32_t)(vv - 2);                 // remaining symbols -> 8,6,4,2 bits
+    const uint32_t size = 1u << sh;                              // 256,64,16,4
+    const uint32_t base = 3u * (340u - ((4u << sh) - 4u) / 3u); // 0,768,960,1008 for v = 6,5,4,3  (340 = 256+64+16+4)
+    const uint32_t idx = base + (pi - 1u) * size + ((code >> 4) & (size - 1u));
+    return tab[(pi != 0u && vv >= 3) ? idx : (uint32_t)(RBS_TAB_WORDS - 1)];
 }
 
 #define FPT (PHX_TILE / PHX_FEAT_THREADS) // tile positions per thread in the output stage (consecutive)
-#define FIT 9 // window indices per thread in the scan stages (consecutive; a multiple of 3, FIT * threads >= FW)
-static_assert(FIT % 3 == 0 && FIT * PHX_FEAT_THREADS >= PHX_TILE + 2 * PHX_HALO, "FIT");
+#define FIT 9                              // window indices per thread in the scan stages (consecutive, multiple of 3)
+#define FWX 1665                           // staged window: 64 halo + 1536 + 65 halo = 9 * 185 indices
+#define FACT (FWX / FIT)                   // threads that own window indices
+static_assert(FWX % FIT == 0 && FIT % 3 == 0 && FWX >= PHX_TILE + 2 * PHX_HALO && FACT <= PHX_FEAT_THREADS, "feature window");
+#define SCPAD 8 // s_code / s_W carry 8 "outside" entries on either side so that the rolling scans need no bounds checks
+
+// per-position outputs of one thread (FPT consecutive positions).  FULL: the whole tile (and the 2 bases after
+// it) lies inside the contig, so no position needs a bounds test.
+template <bool FULL>
+__device__ __forceinline__ void feature_outputs(int tid, int p0, int L, const DParams *P, const uint8_t *sc, const uint8_t *sW, const uint32_t *s_AF,
+                                                const uint32_t *s_AR, uint32_t *s_hist, uint8_t *o_cls, uint8_t *o_gcc, uint8_t *o_cnt, uint16_t *o_rbs,
+                                                uint32_t &nz0) {
+    const int j0 = tid * FPT;
+    const int x0 = PHX_HALO + j0;
+    uint32_t af[FPT + 12], ar[FPT + 12]; // af[m] = AF[x0 - 15 + m], ar[m] = AR[x0 + 3 + m]
+#pragma unroll
+    for (int m = 0; m < FPT + 12; m++) { af[m] = s_AF[x0 - 15 + m]; ar[m] = s_AR[x0 + 3 + m]; }
+    uint32_t cd[FPT + 2], wv[FPT + 2];
+#pragma unroll
+    for (int m = 0; m < FPT + 2; m++) { cd[m] = sc[SCPAD + x0 + m]; wv[m] = sW[SCPAD + x0 + m]; }
+#pragma unroll
+    for (int j = 0; j < FPT; j++) {
+        const int p = p0 + j0 + j;
+        const bool in = FULL || p < L, codon = FULL || p <= L - 3;
+        const uint32_t c0 = cd[j], c1 = cd[j + 1], c2 = cd[j + 2];
+        // codon class: entry 64 of the tables is "no codon" (ambiguous base, or past the end)
+        const uint32_t ci = (codon && !((c0 | c1 | c2) & 4u)) ? ((c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4)) : 64u;
+        const uint32_t cls = P->cls_tab[ci], atg = P->atg_tab[ci];
+        const int w0 = (int)wv[j], w1 = (int)wv[j + 1], w2 = (int)wv[j + 2];
+        const uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
+        const uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
+        const uint32_t gcc = codon ? (f | (r << 4)) : 0u;
+        // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7 (codes a0 c1 t2 g3 -> shifts 0,6,2,4)
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t x = k == 0 ? c0 : (k == 1 ? c1 : c2);
+            cnt += ((x & 4u) ? 0u : 1u) << ((0x4260u >> (4 * (x & 3u))) & 15u);
+        }
+        // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21]);
+        // offsets 3-4 use class byte 0, 5-10 byte 1, 11-12 byte 2, 13-15 byte 3
+        uint32_t bf = 0, br = 0;
+#pragma unroll
+        for (int o = 3; o <= 15; o++) {
+            const int sh = 8 * (o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)));
+            const uint32_t sf = (af[15 + j - o] >> sh) & 0xffu, sr = (ar[j + o - 3] >> sh) & 0xffu;
+            bf = sf > bf ? sf : bf;
+            br = sr > br ? sr : br;
+        }
+        const bool fwin = in && p >= 20; // background: full-length forward window i = p-20 (functions.py:168)
+        bf = fwin ? bf : 0u;
+        br = in ? br : 0u;
+        nz0 += (fwin && bf == 0 ? 1u : 0u) + (in && br == 0 ? 1u : 0u); // bin 0 is by far the most frequent: counted per thread
+        if (bf) atomicAdd(&s_hist[bf], 1u);
+        if (br) atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
+        o_cls[j0 + j] = (uint8_t)(in ? cls : 0u);
+        o_gcc[j0 + j] = (uint8_t)gcc;
+        o_cnt[j0 + j] = (uint8_t)(in ? cnt : 0u);
+        o_rbs[j0 + j] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
+    }
+}
 
 __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const DTile *__restrict__ tiles, int n_tiles) {
-    __shared__ uint8_t s_code[FW + 8];
-    __shared__ uint16_t s_pref[FW];
-    __shared__ uint8_t s_W[FW + 8];
-    __shared__ uint32_t s_AF[FW], s_AR[FW];
-    __shared__ uint32_t s_t6[768], s_t5[192], s_t4[48], s_t3[12];
+    __shared__ uint8_t s_code[FWX + 2 * SCPAD];
+    __shared__ uint16_t s_pref[FWX];
+    __shared__ uint8_t s_W[FWX + 2 * SCPAD];
+    __shared__ uint32_t s_AF[FWX], s_AR[FWX];
+    __shared__ uint32_t s_tab[RBS_TAB_WORDS];
+    __shared__ uint8_t s_lut[256];
     __shared__ __align__(16) uint8_t o_cls[PHX_TILE], o_gcc[PHX_TILE], o_cnt[PHX_TILE];
     __shared__ __align__(16) uint16_t o_rbs[PHX_TILE];
     __shared__ uint32_t s_hist[28];
@@ -154,164 +215,130 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     __shared__ uint32_t s_gc, s_bad;
 
     const int tid = threadIdx.x;
-    // the motif tables are loaded once per workgroup; the workgroup then walks over tiles (grid-stride)
-    for (int i = tid; i < 768; i += PHX_FEAT_THREADS) s_t6[i] = b.rbs_t6[i];
-    if (tid < 192) s_t5[tid] = b.rbs_t5[tid];
-    if (tid < 48) s_t4[tid] = b.rbs_t4[tid];
-    if (tid < 12) s_t3[tid] = b.rbs_t3[tid];
+    // once per workgroup: the motif table and the ASCII -> base-code table (bit4 = letter outside the alphabet);
+    // the workgroup then walks over tiles (grid-stride)
+    for (int i = tid; i < 768; i += PHX_FEAT_THREADS) s_tab[i] = b.rbs_t6[i];
+    if (tid < 192) s_tab[768 + tid] = b.rbs_t5[tid];
+    if (tid < 48) s_tab[960 + tid] = b.rbs_t4[tid];
+    if (tid < 12) s_tab[1008 + tid] = b.rbs_t3[tid];
+    if (tid == 0) s_tab[RBS_TAB_WORDS - 1] = 0;
+    {
+        bool bad = false;
+        const uint32_t c = base_code((uint32_t)tid, bad);
+        s_lut[tid] = (uint8_t)(c | (bad ? 16u : 0u));
+    }
     const DParams *P = b.params;
+    // the ASCII of the next tile is fetched into registers while the current tile is processed
+    constexpr int NLD = (FWX + 2 * SCPAD + PHX_FEAT_THREADS - 1) / PHX_FEAT_THREADS;
+    uint8_t r_asc[NLD];
+    auto fetch = [&](int t) {
+        const DTile tl = tiles[t];
+        const DMeta *m = &b.meta[tl.contig];
+        const int Ln = m->L;
+        const uint8_t *__restrict__ asc = b.ascii + m->off;
+#pragma unroll
+        for (int j = 0; j < NLD; j++) {
+            const int idx = tid + j * PHX_FEAT_THREADS - SCPAD;
+            const int p = tl.p0 - PHX_HALO + idx;
+            const bool in = idx >= 0 && idx < FWX && p >= 0 && p < Ln;
+            r_asc[j] = in ? asc[p] : (uint8_t)0; // 0 is not a nucleotide letter: maps to "outside" below
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
     for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
         const DTile tile = tiles[ti];
         DMeta *meta = &b.meta[tile.contig];
         const int L = meta->L;
         const int64_t off = meta->off;
         const int p0 = tile.p0;
-        const uint8_t *__restrict__ ascii = b.ascii + off;
         __syncthreads(); // the previous tile's LDS is no longer read
         if (tid < 28) s_hist[tid] = 0;
         if (tid == 0) { s_gc = 0; s_bad = 0; }
 
-        // 1. stage the tile (+halo) as base codes
-        bool bad = false;
-        uint32_t mygc = 0;
-        for (int idx = tid; idx < FW + 8; idx += PHX_FEAT_THREADS) {
-            const int p = p0 - PHX_HALO + idx;
-            uint32_t c;
-            if (idx >= FW || p < 0 || p >= L) c = 8u | 4u;
-            else {
-                c = base_code(ascii[p], bad);
-                if (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE) mygc += c & 1u;
-            }
-            s_code[idx] = (uint8_t)c;
-        }
-        __syncthreads();
-
-        // 2. per-residue exclusive GC prefix over the window (three interleaved sums, packed 3 x 10 bit);
-        //    every thread owns FIT consecutive window indices (FIT is a multiple of 3)
-        const int i0 = tid * FIT;
-        {
-            uint32_t loc = 0;
+        // 1. stage the tile (+halo) as base codes; positions outside the contig (and the pads) read as "outside"
+        uint32_t badacc = 0, mygc = 0;
 #pragma unroll
-            for (int k = 0; k < FIT; k++) {
-                const int idx = i0 + k;
-                if (idx < FW) loc += (uint32_t)(s_code[idx] & 1u) << (10 * (k % 3));
+        for (int j = 0; j < NLD; j++) {
+            const int x = tid + j * PHX_FEAT_THREADS;
+            const int idx = x - SCPAD;
+            const int p = p0 - PHX_HALO + idx;
+            const bool in = idx >= 0 && idx < FWX && p >= 0 && p < L;
+            const uint32_t c = in ? s_lut[r_asc[j]] : 12u;
+            badacc |= c;
+            mygc += (idx >= PHX_HALO && idx < PHX_HALO + PHX_TILE) ? (c & 1u) : 0u;
+            if (x < FWX + 2 * SCPAD) s_code[x] = (uint8_t)(c & 15u);
+        }
+        if (ti + (int)gridDim.x < n_tiles) fetch(ti + gridDim.x);
+        __syncthreads();
+        const uint8_t *sc = s_code; // sc[SCPAD + idx]
+
+        {
+            // 2a. per-residue GC counts of this thread's FIT consecutive window indices (packed 3 x 10 bit)
+            uint32_t loc = 0;
+            if (tid < FACT) {
+                const int i0 = tid * FIT;
+#pragma unroll
+                for (int k = 0; k < FIT; k++) loc += (uint32_t)(sc[SCPAD + i0 + k] & 1u) << (10 * (k % 3));
             }
             uint32_t tot;
-            uint32_t ex = block_excl_scan<PHX_FEAT_THREADS>(loc, s_scan, &tot);
-            uint32_t run[3] = {ex & 1023u, (ex >> 10) & 1023u, (ex >> 20) & 1023u};
+            const uint32_t ex = block_excl_scan<PHX_FEAT_THREADS>(loc, s_scan, &tot);
+            if (tid < FACT) {
+                const int i0 = tid * FIT;
+                // 2b. exclusive per-residue GC prefix over the window
+                uint32_t run[3] = {ex & 1023u, (ex >> 10) & 1023u, (ex >> 20) & 1023u};
 #pragma unroll
-            for (int k = 0; k < FIT; k++) {
-                const int idx = i0 + k;
-                if (idx < FW) {
-                    s_pref[idx] = (uint16_t)run[k % 3];
-                    run[k % 3] += s_code[idx] & 1u;
+                for (int k = 0; k < FIT; k++) {
+                    s_pref[i0 + k] = (uint16_t)run[k % 3];
+                    run[k % 3] += sc[SCPAD + i0 + k] & 1u;
                 }
             }
         }
-        // 3a. k-mer class scores with rolling 6-mer codes over the thread's consecutive indices:
-        //     leftward 6-mer s[k] = dna[y-k] (forward windows) scanning up, rightward complemented 6-mer
-        //     s[k] = comp(dna[y+k]) (reverse windows) scanning down
-        {
+        __syncthreads();
+        if (tid < FACT) {
+            // 3a. k-mer class scores with rolling 6-mer codes over the thread's consecutive indices:
+            //     leftward 6-mer s[k] = dna[y-k] (forward windows) scanning up, rightward complemented 6-mer
+            //     s[k] = comp(dna[y+k]) (reverse windows) scanning down
+            const int i0 = tid * FIT;
             uint32_t code = 0; int v = 0;
 #pragma unroll
             for (int k = 5; k >= 1; k--) {
-                const int idx = i0 - k;
-                const uint32_t c = idx >= 0 ? s_code[idx] : 12u;
+                const uint32_t c = sc[SCPAD + i0 - k];
                 code = ((code << 2) | (c & 3u)) & 4095u;
-                v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+                v = (c & 4u) ? 0 : v + 1;
             }
 #pragma unroll
             for (int k = 0; k < FIT; k++) {
-                const int idx = i0 + k;
-                if (idx < FW) {
-                    const uint32_t c = s_code[idx];
-                    code = ((code << 2) | (c & 3u)) & 4095u;
-                    v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
-                    s_AF[idx] = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
-                }
+                const uint32_t c = sc[SCPAD + i0 + k];
+                code = ((code << 2) | (c & 3u)) & 4095u;
+                v = (c & 4u) ? 0 : v + 1;
+                s_AF[i0 + k] = kmer_lookup(s_tab, code, v);
             }
             code = 0; v = 0;
-            const int ie = i0 + FIT - 1; // last index of this thread
 #pragma unroll
             for (int k = 5; k >= 1; k--) {
-                const int idx = ie + k;
-                const uint32_t c = idx < FW + 8 ? s_code[idx] : 12u;
+                const uint32_t c = sc[SCPAD + i0 + FIT - 1 + k];
                 code = ((code << 2) | ((c & 3u) ^ 2u)) & 4095u;
-                v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
+                v = (c & 4u) ? 0 : v + 1;
             }
 #pragma unroll
             for (int k = FIT - 1; k >= 0; k--) {
-                const int idx = i0 + k;
-                if (idx < FW) {
-                    const uint32_t c = s_code[idx];
-                    code = ((code << 2) | ((c & 3u) ^ 2u)) & 4095u;
-                    v = (c & 4u) ? 0 : (v < 6 ? v + 1 : 6);
-                    s_AR[idx] = kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v);
-                }
+                const uint32_t c = sc[SCPAD + i0 + k];
+                code = ((code << 2) | ((c & 3u) ^ 2u)) & 4095u;
+                v = (c & 4u) ? 0 : v + 1;
+                s_AR[i0 + k] = kmer_lookup(s_tab, code, v);
             }
         }
-        __syncthreads();
-        // 3b. W(q) = GC count over q+3m, m in [-19,20] (gc_frame_plot.py:44-59)
-        for (int idx = PHX_HALO + tid; idx < PHX_HALO + PHX_TILE + 8; idx += PHX_FEAT_THREADS)
-            s_W[idx] = (uint8_t)(idx + 60 < FW ? s_pref[idx + 60] + (s_code[idx + 60] & 1u) - s_pref[idx - 57] : 0);
+        // 3b. W(q) = GC count over q+3m, m in [-19,20] (gc_frame_plot.py:44-59), for the tile and 8 positions beyond
+        for (int idx = PHX_HALO + tid; idx < PHX_HALO + PHX_TILE + 8; idx += PHX_FEAT_THREADS) {
+            const int hi = idx + 60 < FWX ? idx + 60 : FWX - 1;
+            s_W[SCPAD + idx] = (uint8_t)(s_pref[hi] + (sc[SCPAD + hi] & 1u) - s_pref[idx - 57]);
+        }
         __syncthreads();
 
         // 4. per-position outputs; every thread owns FPT consecutive positions, the k-mer scores it needs sit in registers
         uint32_t nz0 = 0;
-        {
-            const int j0 = tid * FPT;
-            const int x0 = PHX_HALO + j0;
-            uint32_t af[FPT + 12], ar[FPT + 12]; // af[m] = AF[x0 - 15 + m], ar[m] = AR[x0 + 3 + m]
-#pragma unroll
-            for (int m = 0; m < FPT + 12; m++) { af[m] = s_AF[x0 - 15 + m]; ar[m] = s_AR[x0 + 3 + m]; }
-            uint32_t cd[FPT + 2], wv[FPT + 2];
-#pragma unroll
-            for (int m = 0; m < FPT + 2; m++) { cd[m] = s_code[x0 + m]; wv[m] = s_W[x0 + m]; }
-#pragma unroll
-            for (int j = 0; j < FPT; j++) {
-                const int p = p0 + j0 + j;
-                uint32_t cls = 0, atg = 0, gcc = 0, cnt = 0, bf = 0, br = 0;
-                if (p < L) {
-                    const uint32_t c0 = cd[j], c1 = cd[j + 1], c2 = cd[j + 2];
-                    if (p <= L - 3) {
-                        if (!((c0 | c1 | c2) & 4u)) {
-                            const uint32_t ci = (c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4);
-                            cls = P->cls_tab[ci];
-                            atg = P->atg_tab[ci];
-                        }
-                        const int w0 = (int)wv[j], w1 = (int)wv[j + 1], w2 = (int)wv[j + 2];
-                        const uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
-                        const uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
-                        gcc = f | (r << 4);
-                    }
-                    // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7 (codes a0 c1 t2 g3)
-                    const uint32_t cc[3] = {c0, c1, c2};
-#pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        if (!(cc[k] & 4u)) {
-                            const uint32_t x = cc[k] & 3u;
-                            cnt += 1u << (x == 0 ? 0 : (x == 2 ? 2 : (x == 3 ? 4 : 6)));
-                        }
-                    // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21]);
-                    // offsets 3-4 use class byte 0, 5-10 byte 1, 11-12 byte 2, 13-15 byte 3
-#pragma unroll
-                    for (int o = 3; o <= 15; o++) {
-                        const int sh = 8 * (o <= 4 ? 0 : (o <= 10 ? 1 : (o <= 12 ? 2 : 3)));
-                        const uint32_t sf = (af[15 + j - o] >> sh) & 0xffu, sr = (ar[j + o - 3] >> sh) & 0xffu;
-                        bf = sf > bf ? sf : bf;
-                        br = sr > br ? sr : br;
-                    }
-                    if (p >= 20) { // background: full-length forward window i = p-20 (functions.py:168)
-                        if (bf) atomicAdd(&s_hist[bf], 1u); else nz0++;
-                    } else bf = 0;
-                    if (br) atomicAdd(&s_hist[br], 1u); else nz0++; // background: reverse-complemented window i = p (functions.py:169)
-                }
-                o_cls[j0 + j] = (uint8_t)cls;
-                o_gcc[j0 + j] = (uint8_t)gcc;
-                o_cnt[j0 + j] = (uint8_t)cnt;
-                o_rbs[j0 + j] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
-            }
-        }
+        if (p0 + PHX_TILE + 2 <= L) feature_outputs<true>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_cnt, o_rbs, nz0);
+        else feature_outputs<false>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_cnt, o_rbs, nz0);
         // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
         // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
         if (L - 1 >= p0 && L - 1 < p0 + PHX_TILE) {
@@ -326,20 +353,20 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
                     if (vmax > 6) vmax = 6;
                     uint32_t code = 0; int v = 0; bool ok = true;
                     for (int k = 0; k < vmax; k++) {
-                        uint32_t c = s_code[ie - o - k];
+                        const uint32_t c = sc[SCPAD + ie - o - k];
                         ok = ok && !(c & 4u);
                         if (ok) v++;
                         code |= (c & 3u) << (2 * k);
                     }
-                    uint32_t sc = (kmer_lookup(s_t6, s_t5, s_t4, s_t3, code, v) >> (8 * off_class(o))) & 0xffu;
-                    best = sc > best ? sc : best;
+                    const uint32_t scv = (kmer_lookup(s_tab, code, v) >> (8 * off_class(o))) & 0xffu;
+                    best = scv > best ? scv : best;
                 }
                 atomicAdd(&s_hist[best], 1u);
             }
         }
         if (mygc) atomicAdd(&s_gc, mygc);
         if (nz0) atomicAdd(&s_hist[0], nz0);
-        if (bad) s_bad = 1;
+        if (badacc & 16u) s_bad = 1;
         __syncthreads();
         // 5. write-out.  Full tiles with 16-byte aligned rows go out as uint4 (coalesced 1 KiB per wave instruction).
         const bool vec = p0 + PHX_TILE <= L && ((off + p0) & 15) == 0;
@@ -368,8 +395,7 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
             const int wbase = p0 / 192;
             for (int pair = wv; pair < 24; pair += PHX_FEAT_THREADS / 64) {
                 const int f = pair >> 3, wi = pair & 7;
-                const int j = f + 3 * (64 * wi + lane);
-                const uint32_t c = (p0 + j <= L - 3) ? (o_cls[j] & 7u) : 0u;
+                const uint32_t c = o_cls[f + 3 * (64 * wi + lane)] & 7u;
                 const uint64_t m1 = __ballot(c == CLS_FS), m2 = __ballot(c == CLS_RS), m3 = __ballot(c == CLS_FT), m4 = __ballot(c == CLS_RT);
                 if (lane == 0) {
                     bits[(size_t)(0 * 3 + f) * nw + wbase + wi] = m1;
