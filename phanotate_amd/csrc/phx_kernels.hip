@@ -1031,105 +1031,112 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
         __syncthreads();
         for (int k = threadIdx.x; k < nst; k += NT) { s_pos[k] = npos[lo + k]; s_info[k] = ninfo[lo + k]; s_oth[k] = nother[lo + k]; s_o[k] = no[lo + k]; }
         __syncthreads();
-        auto POS = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_pos[k] : npos[u]; };
-        auto INFO = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_info[k] : ninfo[u]; };
-        auto OTH = [&](int u) -> int { const int k = u - lo; return (k >= 0 && k < nst) ? s_oth[k] : nother[u]; };
-        auto NO = [&](int u) -> double { const int k = u - lo; return (k >= 0 && k < nst) ? s_o[k] : no[u]; };
+        // Does every +-500 bp scan of this block stay inside the staged range?  (block-uniform; practically always)
+        const int vfirst = base < ncds ? base : ncds - 1, vlast = base + NT - 1 < ncds ? base + NT - 1 : ncds - 1;
+        const bool fits = nst > 0 && vfirst >= 0 && (lo == 0 || s_pos[vfirst - lo] - s_pos[0] >= 500) && (hi == ncds || s_pos[nst - 1] - s_pos[vlast - lo] >= 500);
+        auto node_edges = [&](auto POS, auto INFO, auto OTH, auto NO) {
         const int v = base + (int)threadIdx.x;
-        EdgeSink sink;
-        sink.n = 0;
-        sink.defer = b.defer_overlap != 0;
-        if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
-        if (v < V && v != SRC) {
-            if (v == TGT) {
-                // functions.py:449-452
-                for (int u = ncds - 1; u >= 0 && L - npos[u] <= 2000; u--) {
-                    const int t = NTYPE(ninfo[u]), f = NFRAME(ninfo[u]);
-                    if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, gap(L - npos[u], false));
-                }
-            } else {
-                const int t = NTYPE(INFO(v)), f = NFRAME(INFO(v)), pos = POS(v);
-                const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
-                if (!open) {
-                    // ORF edges, functions.py:311-318
-                    if (t == 1) { // forward stop: one edge per start of the group
-                        const DGrp G = grp[LINK_IDX(nlink[v])];
-                        for (int k = 0; k < G.n; k++) emit_edge<FILL>(sink, orf[G.orf_begin + k].node, orf[G.orf_begin + k].weight);
-                    } else { // reverse start: from the group's stop node
-                        const DOrf *r = &orf[LINK_IDX(nlink[v])];
-                        emit_edge<FILL>(sink, grp[r->grp].node, r->weight);
+            EdgeSink sink;
+            sink.n = 0;
+            sink.defer = b.defer_overlap != 0;
+            if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
+            if (v < V && v != SRC) {
+                if (v == TGT) {
+                    // functions.py:449-452
+                    for (int u = ncds - 1; u >= 0 && L - npos[u] <= 2000; u--) {
+                        const int t = NTYPE(ninfo[u]), f = NFRAME(ninfo[u]);
+                        if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, gap(L - npos[u], false));
                     }
                 } else {
-                    const int my_other = OTH(v);
-                    const double my_o = NO(v);
-                    if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
-                    // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
-                    for (int u = v - 1; u >= 0; u--) {
-                        const int d = pos - POS(u);
-                        if (d >= 500) break;
-                        if (d <= 0) continue;
-                        const int iu = INFO(u);
-                        const int lt = NTYPE(iu), lf = NFRAME(iu);
-                        if (t == 0) { // v = forward start
-                            if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
-                            else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, gap(d - 3, true));
-                        } else { // v = reverse stop
-                            if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
-                            else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, true));
+                    const int t = NTYPE(INFO(v)), f = NFRAME(INFO(v)), pos = POS(v);
+                    const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
+                    if (!open) {
+                        // ORF edges, functions.py:311-318
+                        if (t == 1) { // forward stop: one edge per start of the group
+                            const DGrp G = grp[LINK_IDX(nlink[v])];
+                            for (int k = 0; k < G.n; k++) emit_edge<FILL>(sink, orf[G.orf_begin + k].node, orf[G.orf_begin + k].weight);
+                        } else { // reverse start: from the group's stop node
+                            const DOrf *r = &orf[LINK_IDX(nlink[v])];
+                            emit_edge<FILL>(sink, grp[r->grp].node, r->weight);
                         }
-                    }
-                    // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
-                    for (int u = v + 1; u < ncds; u++) {
-                        const int r = POS(u);
-                        const int d = r - pos;
-                        if (d >= 500) break;
-                        if (d <= 0) continue;
-                        const int iu = INFO(u);
-                        const int rt = NTYPE(iu), rf = NFRAME(iu);
-                        const int r_other = OTH(u);
-                        const double ps = (my_o + NO(u)) / 2.0; // ave([o1,o2]), functions.py:385
-                        if (t == 1) { // v = reverse stop (l), lf < 0
-                            if (rt == 0 && rf < 0) { // same strand: right is a reverse start
-                                if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
-                            } else if (rt == 1 && rf > 0) { // right is a forward stop
-                                if (r_other + 3 < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
-                            }
-                        } else { // v = forward start (l), lf > 0
-                            if (rt == 1 && rf > 0) { // same strand: right is a forward stop
-                                if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
-                            } else if (rt == 0 && rf < 0) { // right is a reverse start
-                                if (r_other < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
+                    } else {
+                        const int my_other = OTH(v);
+                        const double my_o = NO(v);
+                        if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
+                        // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
+                        for (int u = v - 1; u >= 0; u--) {
+                            const int d = pos - POS(u);
+                            if (d >= 500) break;
+                            if (d <= 0) continue;
+                            const int iu = INFO(u);
+                            const int lt = NTYPE(iu), lf = NFRAME(iu);
+                            if (t == 0) { // v = forward start
+                                if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
+                                else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, gap(d - 3, true));
+                            } else { // v = reverse stop
+                                if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
+                                else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, true));
                             }
                         }
-                    }
-                    // long non-coding bridges, functions.py:334-354 (v as right node)
-                    for (int k = 0; k < nbr && k < PHX_MAX_BRIDGE; k++) {
-                        const int last = meta->bridge[k].last, bs = meta->bridge[k].base;
-                        if (!(bs - 1 <= pos && pos < bs + 500)) continue;
-                        // left nodes with last-500 < l <= last+1 : binary search the first pos > last-500
-                        int lo = 0, hi = ncds;
-                        while (lo < hi) { int m = (lo + hi) >> 1; if (npos[m] > last - 500) hi = m; else lo = m + 1; }
-                        for (int u = lo; u < ncds && npos[u] <= last + 1; u++) {
-                            const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
-                            const int d = pos - npos[u];
-                            bool hit = false, diff = false;
-                            if (t == 0) { // v forward start
-                                if (lt == 1 && lf > 0) hit = true;
-                                else if (lt == 0 && lf < 0) { hit = true; diff = true; }
-                            } else { // v reverse stop
-                                if (lt == 0 && lf < 0) hit = true;
-                                else if (lt == 1 && lf > 0) { hit = true; diff = true; }
+                        // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
+                        for (int u = v + 1; u < ncds; u++) {
+                            const int r = POS(u);
+                            const int d = r - pos;
+                            if (d >= 500) break;
+                            if (d <= 0) continue;
+                            const int iu = INFO(u);
+                            const int rt = NTYPE(iu), rf = NFRAME(iu);
+                            const int r_other = OTH(u);
+                            const double ps = (my_o + NO(u)) / 2.0; // ave([o1,o2]), functions.py:385
+                            if (t == 1) { // v = reverse stop (l), lf < 0
+                                if (rt == 0 && rf < 0) { // same strand: right is a reverse start
+                                    if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
+                                } else if (rt == 1 && rf > 0) { // right is a forward stop
+                                    if (r_other + 3 < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
+                                }
+                            } else { // v = forward start (l), lf > 0
+                                if (rt == 1 && rf > 0) { // same strand: right is a forward stop
+                                    if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
+                                } else if (rt == 0 && rf < 0) { // right is a reverse start
+                                    if (r_other < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
+                                }
                             }
-                            if (hit) {
-                                if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
-                                emit_edge<FILL>(sink, u, gap(d - 3, diff));
+                        }
+                        // long non-coding bridges, functions.py:334-354 (v as right node)
+                        for (int k = 0; k < nbr && k < PHX_MAX_BRIDGE; k++) {
+                            const int last = meta->bridge[k].last, bs = meta->bridge[k].base;
+                            if (!(bs - 1 <= pos && pos < bs + 500)) continue;
+                            // left nodes with last-500 < l <= last+1 : binary search the first pos > last-500
+                            int lo = 0, hi = ncds;
+                            while (lo < hi) { int m = (lo + hi) >> 1; if (npos[m] > last - 500) hi = m; else lo = m + 1; }
+                            for (int u = lo; u < ncds && npos[u] <= last + 1; u++) {
+                                const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
+                                const int d = pos - npos[u];
+                                bool hit = false, diff = false;
+                                if (t == 0) { // v forward start
+                                    if (lt == 1 && lf > 0) hit = true;
+                                    else if (lt == 0 && lf < 0) { hit = true; diff = true; }
+                                } else { // v reverse stop
+                                    if (lt == 0 && lf < 0) hit = true;
+                                    else if (lt == 1 && lf > 0) { hit = true; diff = true; }
+                                }
+                                if (hit) {
+                                    if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
+                                    emit_edge<FILL>(sink, u, gap(d - 3, diff));
+                                }
                             }
                         }
                     }
                 }
             }
-        }
-        if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
+            if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
+        };
+        if (fits)
+            node_edges([&](int u) -> int { return s_pos[u - lo]; }, [&](int u) -> int { return s_info[u - lo]; },
+                       [&](int u) -> int { return s_oth[u - lo]; }, [&](int u) -> double { return s_o[u - lo]; });
+        else
+            node_edges([&](int u) -> int { return npos[u]; }, [&](int u) -> int { return ninfo[u]; },
+                       [&](int u) -> int { return nother[u]; }, [&](int u) -> double { return no[u]; });
     }
     if (parallel) atomicMin(&meta->status, PHX_S_PARALLEL);
 }
