@@ -229,7 +229,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) { c->tiles.push_back(DTile{i, (int32_t)p0}); nt++; }
         m.nw = 8 * nt; // every feature tile writes 8 words per (class, frame)
         m.bits_off = words; m.item_off = items;
-        words += 12 * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
+        words += PHX_BITMAP_WORDS_PER_NW * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
         off += L;
         off = (off + 15) & ~(int64_t)15; // 16-byte aligned rows let the feature kernel store uint4
     }
@@ -244,8 +244,6 @@ int ensure_position_buffers(phx_ctx *c) {
     const size_t T = (size_t)c->totalL + 64;
     int rc;
     if ((rc = ensure(c, c->b_cls, T))) return rc;
-    if ((rc = ensure(c, c->b_gcc, T))) return rc;
-    if ((rc = ensure(c, c->b_cnt, T))) return rc;
     if ((rc = ensure(c, c->b_cov, T))) return rc;
     if ((rc = ensure(c, c->b_rbs, T * 2))) return rc;
     if ((rc = ensure(c, c->b_linkF, T * 4))) return rc;
@@ -649,7 +647,22 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
     TAP_PRE(c, contig);
     const size_t L = (size_t)m.L;
     if (cls) HIPCHK(c, hipMemcpy(cls, (uint8_t *)c->b_cls.p + m.off, L, hipMemcpyDeviceToHost));
-    if (gcc) HIPCHK(c, hipMemcpy(gcc, (uint8_t *)c->b_gcc.p + m.off, L, hipMemcpyDeviceToHost));
+    if (gcc) { // the device keeps the GC-frame classes bit-sliced: 9 forward + 9 reverse class bitmaps per frame
+        const size_t nw = (size_t)m.nw;
+        std::vector<uint64_t> bits((size_t)PHX_BITMAP_WORDS_PER_NW * nw);
+        if (nw) HIPCHK(c, hipMemcpy(bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, bits.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < L; p++) {
+            const size_t f = p % 3, k = p / 3;
+            uint8_t g = 0;
+            if (p + 3 <= L) {
+                auto bit = [&](int id) { return (int)((bits[((size_t)id * 3 + f) * nw + (k >> 6)] >> (k & 63)) & 1ull); };
+                const int fmx = bit(4) ? 0 : (bit(5) ? 1 : 2), fmn = bit(6) ? 0 : (bit(7) ? 1 : 2);
+                const int rmx = bit(8) ? 0 : (bit(9) ? 1 : 2), rmn = bit(10) ? 0 : (bit(11) ? 1 : 2);
+                g = (uint8_t)((fmx * 3 + fmn) | ((rmx * 3 + rmn) << 4));
+            }
+            gcc[p] = g;
+        }
+    }
     if (binF || binR) {
         std::vector<uint16_t> r(L);
         HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));

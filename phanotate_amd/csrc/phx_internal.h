@@ -19,6 +19,8 @@
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
 #define PHX_MAX_BRIDGE 16
+#define PHX_N_CODON_BITMAPS 12 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple
+#define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
 
 // codon classes, in the elif order of functions.py:198-215
 #define CLS_NONE 0
@@ -127,7 +129,7 @@ struct DBatch {
     uint8_t *cls, *gcc, *cnt, *cov;
     uint16_t *rbs;
     uint32_t *linkF, *linkR;
-    uint64_t *bits;     // per contig: [class FS,RS,FT,RT][frame 0..2][nw] codon bitmaps, bit k of frame f <-> position f+3k
+    uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
     // per ORF / group
     DOrf *orf;

@@ -149,7 +149,7 @@ static_assert(FWX % FIT == 0 && FIT % 3 == 0 && FWX >= PHX_TILE + 2 * PHX_HALO &
 // it) lies inside the contig, so no position needs a bounds test.
 template <bool FULL>
 __device__ __forceinline__ void feature_outputs(int tid, int p0, int L, const DParams *P, const uint8_t *sc, const uint8_t *sW, const uint32_t *s_AF,
-                                                const uint32_t *s_AR, uint32_t *s_hist, uint8_t *o_cls, uint8_t *o_gcc, uint8_t *o_cnt, uint16_t *o_rbs,
+                                                const uint32_t *s_AR, uint32_t *s_hist, uint8_t *o_cls, uint8_t *o_gcc, uint16_t *o_rbs,
                                                 uint32_t &nz0) {
     const int j0 = tid * FPT;
     const int x0 = PHX_HALO + j0;
@@ -168,16 +168,9 @@ __device__ __forceinline__ void feature_outputs(int tid, int p0, int L, const DP
         const uint32_t ci = (codon && !((c0 | c1 | c2) & 4u)) ? ((c0 & 3u) | ((c1 & 3u) << 2) | ((c2 & 3u) << 4)) : 64u;
         const uint32_t cls = P->cls_tab[ci], atg = P->atg_tab[ci];
         const int w0 = (int)wv[j], w1 = (int)wv[j + 1], w2 = (int)wv[j + 2];
-        const uint32_t f = (uint32_t)((max_idx(w0, w1, w2) - 1) * 3 + (min_idx(w0, w1, w2) - 1));
-        const uint32_t r = (uint32_t)((max_idx(w2, w1, w0) - 1) * 3 + (min_idx(w2, w1, w0) - 1));
-        const uint32_t gcc = codon ? (f | (r << 4)) : 0u;
-        // per-codon unambiguous base counts: a bits0-1, t bits2-3, g bits4-5, c bits6-7 (codes a0 c1 t2 g3 -> shifts 0,6,2,4)
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const uint32_t x = k == 0 ? c0 : (k == 1 ? c1 : c2);
-            cnt += ((x & 4u) ? 0u : 1u) << ((0x4260u >> (4 * (x & 3u))) & 15u);
-        }
+        // 2-bit fields: max_idx-1, min_idx-1 of the forward triple, then of the reversed triple
+        const uint32_t gcc = (uint32_t)(max_idx(w0, w1, w2) - 1) | ((uint32_t)(min_idx(w0, w1, w2) - 1) << 2) |
+                             ((uint32_t)(max_idx(w2, w1, w0) - 1) << 4) | ((uint32_t)(min_idx(w2, w1, w0) - 1) << 6);
         // score_rbs bins: forward window dna[p-20:p+1] (needs p >= 20), reverse window rev_comp(dna[p:p+21]);
         // offsets 3-4 use class byte 0, 5-10 byte 1, 11-12 byte 2, 13-15 byte 3
         uint32_t bf = 0, br = 0;
@@ -196,7 +189,6 @@ __device__ __forceinline__ void feature_outputs(int tid, int p0, int L, const DP
         if (br) atomicAdd(&s_hist[br], 1u); // background: reverse-complemented window i = p (functions.py:169)
         o_cls[j0 + j] = (uint8_t)(in ? cls : 0u);
         o_gcc[j0 + j] = (uint8_t)gcc;
-        o_cnt[j0 + j] = (uint8_t)(in ? cnt : 0u);
         o_rbs[j0 + j] = (uint16_t)(bf | (br << 5) | ((atg & 1u) << 10) | ((atg & 2u) << 10));
     }
 }
@@ -208,7 +200,7 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
     __shared__ uint32_t s_AF[FWX], s_AR[FWX];
     __shared__ uint32_t s_tab[RBS_TAB_WORDS];
     __shared__ uint8_t s_lut[256];
-    __shared__ __align__(16) uint8_t o_cls[PHX_TILE], o_gcc[PHX_TILE], o_cnt[PHX_TILE];
+    __shared__ __align__(16) uint8_t o_cls[PHX_TILE], o_gcc[PHX_TILE];
     __shared__ __align__(16) uint16_t o_rbs[PHX_TILE];
     __shared__ uint32_t s_hist[28];
     __shared__ uint32_t s_scan[PHX_FEAT_THREADS / 64 + 1];
@@ -337,8 +329,8 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
 
         // 4. per-position outputs; every thread owns FPT consecutive positions, the k-mer scores it needs sit in registers
         uint32_t nz0 = 0;
-        if (p0 + PHX_TILE + 2 <= L) feature_outputs<true>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_cnt, o_rbs, nz0);
-        else feature_outputs<false>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_cnt, o_rbs, nz0);
+        if (p0 + PHX_TILE + 2 <= L) feature_outputs<true>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_rbs, nz0);
+        else feature_outputs<false>(tid, p0, L, P, sc, s_W, s_AF, s_AR, s_hist, o_cls, o_gcc, o_rbs, nz0);
         // the last 20 forward background windows are right-truncated: dna[i:i+21] with i > L-21, i.e.
         // s[k] = dna[L-1-k] for k < len = L-i (functions.py:168 with python slice clipping)
         if (L - 1 >= p0 && L - 1 < p0 + PHX_TILE) {
@@ -371,23 +363,20 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
         // 5. write-out.  Full tiles with 16-byte aligned rows go out as uint4 (coalesced 1 KiB per wave instruction).
         const bool vec = p0 + PHX_TILE <= L && ((off + p0) & 15) == 0;
         if (vec) {
-            uint4 *gc4 = (uint4 *)(b.cls + off + p0), *gg4 = (uint4 *)(b.gcc + off + p0), *gn4 = (uint4 *)(b.cnt + off + p0), *gr4 = (uint4 *)(b.rbs + off + p0);
-            for (int i = tid; i < PHX_TILE / 16; i += PHX_FEAT_THREADS) {
-                gc4[i] = ((const uint4 *)o_cls)[i];
-                gg4[i] = ((const uint4 *)o_gcc)[i];
-                gn4[i] = ((const uint4 *)o_cnt)[i];
-            }
+            uint4 *gc4 = (uint4 *)(b.cls + off + p0), *gr4 = (uint4 *)(b.rbs + off + p0);
+            for (int i = tid; i < PHX_TILE / 16; i += PHX_FEAT_THREADS) gc4[i] = ((const uint4 *)o_cls)[i];
             for (int i = tid; i < PHX_TILE / 8; i += PHX_FEAT_THREADS) gr4[i] = ((const uint4 *)o_rbs)[i];
         } else {
             for (int j = tid; j < PHX_TILE && p0 + j < L; j += PHX_FEAT_THREADS) {
                 b.cls[off + p0 + j] = o_cls[j];
-                b.gcc[off + p0 + j] = o_gcc[j];
-                b.cnt[off + p0 + j] = o_cnt[j];
                 b.rbs[off + p0 + j] = o_rbs[j];
             }
         }
-        // start/stop codon bitmaps by wavefront ballot: lane <-> codon, one 64-bit word per (class, frame, 64 codons).
-        // p0 is a multiple of 1536 = 3*512, so codon f+3k of this tile is bit (k & 63) of word p0/192 + k/64.
+        // Bit-sliced outputs by wavefront ballot, one 64-bit word per 64 lanes:
+        //  * codon bitmaps (lane <-> codon k of frame f, position f+3k): start/stop classes and the 9 GC-frame classes of the
+        //    forward and of the reversed triple.  p0 is a multiple of 1536 = 3*512, so codon k of this tile is bit (k & 63)
+        //    of word p0/192 + k/64;
+        //  * base bitmaps (lane <-> position): unambiguous a, c, t, g.
         {
             const int lane = tid & 63, wv = tid >> 6;
             uint64_t *bits = b.bits + meta->bits_off;
@@ -395,14 +384,25 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
             const int wbase = p0 / 192;
             for (int pair = wv; pair < 24; pair += PHX_FEAT_THREADS / 64) {
                 const int f = pair >> 3, wi = pair & 7;
-                const uint32_t c = o_cls[f + 3 * (64 * wi + lane)] & 7u;
-                const uint64_t m1 = __ballot(c == CLS_FS), m2 = __ballot(c == CLS_RS), m3 = __ballot(c == CLS_FT), m4 = __ballot(c == CLS_RT);
-                if (lane == 0) {
-                    bits[(size_t)(0 * 3 + f) * nw + wbase + wi] = m1;
-                    bits[(size_t)(1 * 3 + f) * nw + wbase + wi] = m2;
-                    bits[(size_t)(2 * 3 + f) * nw + wbase + wi] = m3;
-                    bits[(size_t)(3 * 3 + f) * nw + wbase + wi] = m4;
-                }
+                const int j = f + 3 * (64 * wi + lane);
+                const uint32_t c = o_cls[j] & 7u, g = o_gcc[j];
+                uint64_t m[PHX_N_CODON_BITMAPS];
+                m[0] = __ballot(c == CLS_FS); m[1] = __ballot(c == CLS_RS); m[2] = __ballot(c == CLS_FT); m[3] = __ballot(c == CLS_RT);
+                // GC-frame classes as marginals (2-bit fields of g): max_idx == 1, == 2, min_idx == 1, == 2 of the forward and
+                // of the reversed triple (== 3 is the complement)
+                m[4] = __ballot((g & 3u) == 0u); m[5] = __ballot((g & 3u) == 1u); m[6] = __ballot((g & 12u) == 0u); m[7] = __ballot((g & 12u) == 4u);
+                m[8] = __ballot((g & 48u) == 0u); m[9] = __ballot((g & 48u) == 16u); m[10] = __ballot((g & 192u) == 0u); m[11] = __ballot((g & 192u) == 64u);
+                uint64_t mine = 0; // lane id keeps bitmap id's word: one store instruction for all 22 words
+#pragma unroll
+                for (int id = 0; id < PHX_N_CODON_BITMAPS; id++) mine = lane == id ? m[id] : mine;
+                if (lane < PHX_N_CODON_BITMAPS) bits[(size_t)(lane * 3 + f) * nw + wbase + wi] = mine;
+            }
+            uint64_t *bb = bits + (size_t)PHX_N_CODON_BITMAPS * 3 * nw; // base bitmaps: [a,c,t,g][3*nw words over positions]
+            const int pbase = p0 / 64;
+            for (int w = wv; w < PHX_TILE / 64; w += PHX_FEAT_THREADS / 64) {
+                const uint32_t c = sc[SCPAD + PHX_HALO + 64 * w + lane]; // invalid (bit 2) for ambiguity codes and outside the contig
+                const uint64_t ma = __ballot(c == 0u), mc = __ballot(c == 1u), mt = __ballot(c == 2u), mg = __ballot(c == 3u);
+                if (lane < 4) bb[(size_t)lane * 3 * nw + pbase + w] = lane == 0 ? ma : (lane == 1 ? mc : (lane == 2 ? mt : mg));
             }
         }
         if (tid < 28 && s_hist[tid]) atomicAdd(&meta->bg[tid], s_hist[tid]);
@@ -653,98 +653,101 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// ORF statistics, 16 lanes (one DPP row) per ORF: lanes stride the codons, 64-bit packed counters, DPP row
-// sums: GC-frame class histogram (functions.py:286-298) and p_stop (orfs.py:162-173); then 16 lanes per
-// stop-group for the GC frame plot training of functions.py:261-279.
+// ORF statistics on the bit-sliced features, one thread per ORF: the 3x3 GC-frame class histogram over the sense
+// codons (functions.py:286-298) is a popcount over a codon range of 9 class bitmaps, p_stop (orfs.py:162-173) a
+// popcount over a position range of the a/t/g(/c) base bitmaps.  Then one thread per stop-group for the GC frame
+// plot training of functions.py:261-279 (same popcounts over a sub-range of the first 'atg' ORF).
+__device__ __forceinline__ uint32_t popc_range(const uint64_t *__restrict__ B, int lo, int hi) { // set bits with index in [lo, hi]
+    if (hi < lo) return 0u;
+    uint32_t n = 0;
+    for (int w = lo >> 6; w <= (hi >> 6); w++) n += (uint32_t)__popcll(B[w] & range_mask(w, lo, hi));
+    return n;
+}
+// 3x3 histogram (max_idx-1)*3 + (min_idx-1) over the codons [lo, hi] of one frame from the four marginal bitmaps
+// M[0] = max_idx==1, M[1] = max_idx==2, M[2] = min_idx==1, M[3] = min_idx==2 (stride = distance between bitmaps)
+__device__ __forceinline__ void class_hist(const uint64_t *__restrict__ M, size_t stride, int lo, int hi, uint32_t h[9]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) h[i] = 0;
+    if (hi < lo) return;
+    for (int w = lo >> 6; w <= (hi >> 6); w++) {
+        const uint64_t rm = range_mask(w, lo, hi);
+        const uint64_t x0 = M[w], x1 = M[stride + w], n0 = M[2 * stride + w], n1 = M[3 * stride + w];
+        const uint64_t x[3] = {x0 & rm, x1 & rm, ~(x0 | x1) & rm};
+        const uint64_t n[3] = {n0, n1, ~(n0 | n1)};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) h[a * 3 + c] += (uint32_t)__popcll(x[a] & n[c]);
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
-    const int64_t off = meta->off;
-    const uint8_t *__restrict__ gcc = b.gcc + off;
-    const uint8_t *__restrict__ cnt = b.cnt + off;
     DOrf *orf = b.orf + meta->orf_off;
     const DGrp *grp = b.grp + meta->grp_off;
-    const int sub = threadIdx.x & 15;
-    const int gq = (int)blockIdx.y * (NT / 16) + ((int)threadIdx.x >> 4), gstride = (int)gridDim.y * (NT / 16);
+    const int nw = meta->nw;
+    const uint64_t *bits = b.bits + meta->bits_off;
+    const uint64_t *bb = bits + (size_t)PHX_N_CODON_BITMAPS * 3 * nw; // [a,c,t,g][3*nw]
+    const int gtid = (int)blockIdx.y * NT + (int)threadIdx.x, gstride = (int)gridDim.y * NT;
     bool ovf = false;
-    const int norf = meta->n_orf;
-    for (int k0 = 0; k0 < norf; k0 += gstride) { // uniform trip count: DPP needs the whole row active
-        const int k = k0 + gq;
-        const bool on = k < norf;
-        DOrf *r = &orf[on ? k : 0];
+    for (int k = gtid; k < meta->n_orf; k += gstride) {
+        DOrf *r = &orf[k];
         const int start = r->start, stop = r->stop;
         const bool fwd = r->frame > 0;
-        // codons of seq: fwd start..stop (the last one is the stop / last codon, not a sense codon, functions.py:207,290);
-        // rev start, start-3, .., stop (functions.py:220,295)
-        const int ncod = on ? (fwd ? stop - start : start - stop) / 3 + 1 : 0;
+        const int f = (fwd ? r->frame : -r->frame) - 1;
+        // seq = positions [lo1, hi1] (1-based): fwd start..stop+2, rev stop..start+2 (functions.py:207,220)
+        const int lo1 = fwd ? start : stop, hi1 = (fwd ? stop : start) + 2;
+        const int ncod = (hi1 - lo1 + 1) / 3;
         if (ncod > 65535) ovf = true;
-        uint64_t h0 = 0, h1 = 0, h2 = 0; // classes 0-2, 3-5, 6-8 in 21-bit fields
-        uint64_t at = 0, gc_ = 0;        // a | t<<32 ; g | c<<32
-        for (int i = sub; i < ncod; i += 16) {
-            const int base = fwd ? start + 3 * i : start - 3 * i;
-            const uint32_t cb = cnt[base - 1];
-            at += (uint64_t)(cb & 3u) | ((uint64_t)((cb >> 2) & 3u) << 32);
-            gc_ += (uint64_t)((cb >> 4) & 3u) | ((uint64_t)((cb >> 6) & 3u) << 32);
-            if (i < ncod - 1) {
-                const uint32_t g = gcc[base - 1];
-                const uint32_t c = fwd ? (g & 15u) : ((g >> 4) & 15u);
-                const uint64_t inc = 1ull << (21 * (c % 3));
-                h0 += c < 3 ? inc : 0; h1 += (c >= 3 && c < 6) ? inc : 0; h2 += c >= 6 ? inc : 0;
-            }
-        }
-        h0 = row16_sum_u64(h0, sub); h1 = row16_sum_u64(h1, sub); h2 = row16_sum_u64(h2, sub);
-        at = row16_sum_u64(at, sub); gc_ = row16_sum_u64(gc_, sub);
-        if (on && sub == 15) {
-            for (int i = 0; i < 3; i++) {
-                r->hist[i] = (uint16_t)((h0 >> (21 * i)) & 0x1fffff);
-                r->hist[3 + i] = (uint16_t)((h1 >> (21 * i)) & 0x1fffff);
-                r->hist[6 + i] = (uint16_t)((h2 >> (21 * i)) & 0x1fffff);
-            }
-            uint32_t na = (uint32_t)at, nt = (uint32_t)(at >> 32), ng = (uint32_t)gc_, nc = (uint32_t)(gc_ >> 32);
-            if (!fwd) { uint32_t t = na; na = nt; nt = t; ng = nc; } // coding strand: a<->t, g<->c
-            // Orf.p_stop, orfs.py:162-173
-            const double n = (double)(3 * ncod);
-            const double Pa = (double)na / n, Pt = (double)nt / n, Pg = (double)ng / n;
-            r->pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
-            atomicAdd(&meta->tr[r->rbs], 1u); // training_rbs, functions.py:211,224,239,251
-        }
+        // sense codons: fwd codon indices [k0, k1) from start to just before the stop / last codon (functions.py:290);
+        // rev (k0, k1] from just after the stop key up to the start codon (functions.py:295)
+        const int k0 = (lo1 - 1 - f) / 3, k1 = k0 + ncod - 1;
+        const int clo = fwd ? k0 : k0 + 1, chi = fwd ? k1 - 1 : k1;
+        uint32_t h[9];
+        class_hist(bits + (size_t)((fwd ? 4 : 8) * 3 + f) * nw, (size_t)3 * nw, clo, chi, h);
+        for (int cl = 0; cl < 9; cl++) r->hist[cl] = (uint16_t)h[cl];
+        uint32_t na = popc_range(bb + (size_t)0 * 3 * nw, lo1 - 1, hi1 - 1), nc = popc_range(bb + (size_t)1 * 3 * nw, lo1 - 1, hi1 - 1);
+        uint32_t nt = popc_range(bb + (size_t)2 * 3 * nw, lo1 - 1, hi1 - 1), ng = popc_range(bb + (size_t)3 * 3 * nw, lo1 - 1, hi1 - 1);
+        if (!fwd) { const uint32_t t = na; na = nt; nt = t; ng = nc; } // coding strand: a<->t, g<->c
+        // Orf.p_stop, orfs.py:162-173
+        const double n = (double)(3 * ncod);
+        const double Pa = (double)na / n, Pt = (double)nt / n, Pg = (double)ng / n;
+        r->pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
+        atomicAdd(&meta->tr[r->rbs], 1u); // training_rbs, functions.py:211,224,239,251
     }
     // GC frame plot training: per group, the first ORF longest->shortest whose start codon is 'atg'
-    const int ngrp = meta->n_grp;
-    for (int g0 = 0; g0 < ngrp; g0 += gstride) {
-        const int g = g0 + gq;
-        const bool on = g < ngrp;
-        const DGrp G = grp[on ? g : 0];
-        // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46): search from the back
-        int pick = -1;
-        if (on)
-            for (int k = G.n - 1; k >= 0; k--)
-                if (orf[G.orf_begin + k].flags & 1) { pick = k; break; }
-        uint64_t mx = 0, mn = 0; // three 16-bit fields each (index 1..3)
-        if (pick >= 0) {
-            const DOrf *r = &orf[G.orf_begin + pick];
-            const int start = r->start, stop = r->stop;
-            if (start < stop) {
-                const int nn = (int)((double)(stop - start) / 8.0) * 3; // functions.py:270
-                for (int base = start + nn + 3 * sub; base < stop - 36; base += 48) {
-                    const uint32_t c = gcc[base - 1] & 15u;
-                    mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
-                }
-            } else if (stop < start) {
-                const int nn = (int)((double)(start - stop) / 8.0) * 3; // functions.py:275
-                for (int base = start - nn - 3 * sub; base > stop + 36; base -= 48) {
-                    const uint32_t c = (gcc[base - 1] >> 4) & 15u;
-                    mx += 1ull << (16 * (c / 3)); mn += 1ull << (16 * (c % 3));
-                }
-            }
+    for (int g = gtid; g < meta->n_grp; g += gstride) {
+        const DGrp G = grp[g];
+        int pick = -1; // emission order is nearest-first, iter_in is farthest-first (orfs.py:38-46): search from the back
+        for (int k = G.n - 1; k >= 0; k--)
+            if (orf[G.orf_begin + k].flags & 1) { pick = k; break; }
+        if (pick < 0) continue;
+        const DOrf *r = &orf[G.orf_begin + pick];
+        const int start = r->start, stop = r->stop;
+        const bool fwd = start < stop;
+        const int f = (start - 1) % 3;
+        int clo, chi; // codon index range (inclusive) of the bases visited by the training loop
+        if (fwd) { // range(start+n, stop-36, 3), functions.py:270-271
+            const int nn = (int)((double)(stop - start) / 8.0) * 3;
+            clo = (start + nn - 1 - f) / 3;
+            chi = (stop - 36 - 1 - 1 - f) / 3; // last base < stop-36 in this frame
+            if (stop - 36 - 1 - 1 - f < 0) chi = -1;
+        } else if (stop < start) { // range(start-n, stop+36, -3), functions.py:275-276
+            const int nn = (int)((double)(start - stop) / 8.0) * 3;
+            chi = (start - nn - 1 - f) / 3;
+            clo = (stop + 36 - 1 - f) / 3 + 1; // first base > stop+36 in this frame
+        } else continue;
+        uint32_t mx[3] = {0, 0, 0}, mn[3] = {0, 0, 0};
+        {
+            uint32_t h[9];
+            class_hist(bits + (size_t)((fwd ? 4 : 8) * 3 + f) * nw, (size_t)3 * nw, clo, chi, h);
+            for (int cl = 0; cl < 9; cl++) { mx[cl / 3] += h[cl]; mn[cl % 3] += h[cl]; }
         }
-        mx = row16_sum_u64(mx, sub); mn = row16_sum_u64(mn, sub);
-        if (pick >= 0 && sub == 15)
-            for (int i = 0; i < 3; i++) {
-                const uint32_t a = (uint32_t)((mx >> (16 * i)) & 0xffff), c = (uint32_t)((mn >> (16 * i)) & 0xffff);
-                if (a) atomicAdd(&meta->pmax[i + 1], a);
-                if (c) atomicAdd(&meta->pmin[i + 1], c);
-            }
+        for (int i = 0; i < 3; i++) {
+            if (mx[i]) atomicAdd(&meta->pmax[i + 1], mx[i]);
+            if (mn[i]) atomicAdd(&meta->pmin[i + 1], mn[i]);
+        }
     }
     if (ovf) atomicMin(&meta->status, PHX_S_OVERFLOW);
 }
