@@ -26,6 +26,32 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// per-contig records on the host, in pinned memory (they cross PCIe several times per run)
+struct MetaBuf {
+    DMeta *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool assign(size_t count) {
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = count + count / 4 + 16;
+            if (hipHostMalloc((void **)&p, want * sizeof(DMeta), hipHostMallocDefault) != hipSuccess) { p = nullptr; n = 0; return false; }
+            cap = want;
+        }
+        n = count;
+        if (n) memset(p, 0, n * sizeof(DMeta));
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+    DMeta *begin() { return p; }
+    DMeta *end() { return p + n; }
+    const DMeta *begin() const { return p; }
+    const DMeta *end() const { return p + n; }
+    DMeta &operator[](size_t i) { return p[i]; }
+    const DMeta &operator[](size_t i) const { return p[i]; }
+    DMeta *data() { return p; }
+};
+
 } // namespace
 
 struct phx_ctx {
@@ -44,11 +70,12 @@ struct phx_ctx {
     bool uploaded = false, ran = false;
     int64_t totalL = 0, tot_orf = 0, tot_grp = 0, tot_node = 0, tot_edge = 0;
     int n_limbs = 0;
-    std::vector<DMeta> meta;
+    MetaBuf meta;
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_gcc, b_cnt, b_cov, b_rbs, b_linkF, b_linkR, b_orf, b_grp, b_bits, b_item;
+    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_orf, b_grp, b_bits, b_item;
+    int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot;
     void *h_stage = nullptr; // pinned staging for H2D of ASCII
@@ -196,9 +223,9 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
     b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
-    b->cls = (uint8_t *)c->b_cls.p; b->gcc = (uint8_t *)c->b_gcc.p; b->cnt = (uint8_t *)c->b_cnt.p; b->cov = (uint8_t *)c->b_cov.p;
+    b->cls = (uint8_t *)c->b_cls.p;
     b->rbs = (uint16_t *)c->b_rbs.p;
-    b->linkF = (uint32_t *)c->b_linkF.p; b->linkR = (uint32_t *)c->b_linkR.p;
+    b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
     b->npos = (int32_t *)c->b_npos.p; b->ninfo = (int32_t *)c->b_ninfo.p; b->nother = (int32_t *)c->b_nother.p; b->parent = (int32_t *)c->b_parent.p;
@@ -215,9 +242,9 @@ void fill_batch(phx_ctx *c, DBatch *b) {
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     if (n < 0) return PHX_E_ARG;
     c->n = n;
-    c->meta.assign((size_t)n, DMeta());
+    if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
-    int64_t off = 0, words = 0, items = 0;
+    int64_t off = 0, words = 0, items = 0, nbw = 0;
     for (int i = 0; i < n; i++) {
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
@@ -228,12 +255,13 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         int nt = 0;
         for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) { c->tiles.push_back(DTile{i, (int32_t)p0}); nt++; }
         m.nw = 8 * nt; // every feature tile writes 8 words per (class, frame)
-        m.bits_off = words; m.item_off = items;
+        m.bits_off = words; m.item_off = items; m.nbits_off = nbw;
+        nbw += 9 * (int64_t)m.nw;
         words += PHX_BITMAP_WORDS_PER_NW * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
         off += L;
         off = (off + 15) & ~(int64_t)15; // 16-byte aligned rows let the feature kernel store uint4
     }
-    c->tot_words = words; c->tot_items = items;
+    c->tot_words = words; c->tot_items = items; c->tot_nbits = nbw;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
     c->uploaded = true;
     c->ran = false;
@@ -244,10 +272,9 @@ int ensure_position_buffers(phx_ctx *c) {
     const size_t T = (size_t)c->totalL + 64;
     int rc;
     if ((rc = ensure(c, c->b_cls, T))) return rc;
-    if ((rc = ensure(c, c->b_cov, T))) return rc;
     if ((rc = ensure(c, c->b_rbs, T * 2))) return rc;
-    if ((rc = ensure(c, c->b_linkF, T * 4))) return rc;
-    if ((rc = ensure(c, c->b_linkR, T * 4))) return rc;
+    if ((rc = ensure(c, c->b_nbits, (size_t)(c->tot_nbits + 8) * 8))) return rc;
+    if ((rc = ensure(c, c->b_nbase, (size_t)(c->tot_nbits / 3 + 8) * 4))) return rc;
     if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
@@ -364,7 +391,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_gcc, &c->b_cnt, &c->b_cov, &c->b_rbs, &c->b_linkF, &c->b_linkR, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot};
     for (DevBuf *b : all) release(*b);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -373,6 +400,7 @@ void phx_destroy(phx_ctx *c) {
     if (c->d_t4) (void)hipFree(c->d_t4);
     if (c->d_t3) (void)hipFree(c->d_t3);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->meta.release();
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int a = 0; a < 3; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
@@ -422,19 +450,17 @@ int phx_run(phx_ctx *c) {
     if (n == 0) { c->ran = true; return PHX_OK; }
     if ((rc = ensure_position_buffers(c))) return rc;
     hipStream_t s = c->stream;
-    const size_t T = (size_t)c->totalL;
+    (void)0;
     // reset per-contig accumulators (offsets and lengths stay)
     for (DMeta &m : c->meta) {
         DMeta k = m;
         memset(&m, 0, sizeof(m));
-        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off;
+        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
     }
     DBatch b;
     {
         StageTimer t(c, ST_MEMSET);
-        HIPCHK(c, hipMemsetAsync(c->b_linkF.p, 0, T * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_linkR.p, 0, T * 4, s));
-        HIPCHK(c, hipMemsetAsync(c->b_cov.p, 0, T, s));
+        HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
         HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
     }
     {

@@ -422,8 +422,9 @@ __global__ __launch_bounds__(PHX_FEAT_THREADS) void k_features(DBatch b, const D
 struct OrfOut {
     DOrf *orf;
     DGrp *grp;
-    uint32_t *linkF, *linkR;
+    unsigned long long *nbF, *nbR; // node-existence bitmaps over positions: forward-strand / reverse-strand node at that key
 };
+__device__ __forceinline__ void mark_node(unsigned long long *nb, int q) { atomicOr(&nb[q >> 6], 1ull << (q & 63)); }
 struct FrameBits {
     const uint64_t *FS, *RS, *FT, *RT;
     int f;    // 0-based frame = position of codon 0
@@ -471,7 +472,7 @@ __device__ int fwd_group(const FrameBits &F, const uint8_t *__restrict__ cls, co
                     r->startidx = (int8_t)((cls[q] >> 3) & 15);
                     r->flags = (uint8_t)((rbs[q] >> 10) & 1u);
                     r->grp = gidx; r->node = -1;
-                    o.linkF[q] = LINK_START | (uint32_t)(obase + n);
+                    mark_node(o.nbF, q);
                     n++;
                 }
         }
@@ -486,14 +487,14 @@ __device__ int fwd_group(const FrameBits &F, const uint8_t *__restrict__ cls, co
             r->startidx = -1;
             r->flags = (uint8_t)((rbs[q0] >> 10) & 1u);
             r->grp = gidx; r->node = -1;
-            o.linkF[q0] = LINK_START | (uint32_t)(obase + n);
+            mark_node(o.nbF, q0);
         }
         n++;
     }
     if (EMIT && n) {
         DGrp *g = &o.grp[gidx];
         g->stop = p + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = F.f + 1; g->evkey = evkey;
-        o.linkF[p] = LINK_STOP | (uint32_t)gidx;
+        mark_node(o.nbF, p);
     }
     return n;
 }
@@ -526,7 +527,7 @@ __device__ int rev_group(const FrameBits &F, const uint8_t *__restrict__ cls, co
                     r->startidx = (int8_t)((cls[s] >> 3) & 15);
                     r->flags = (uint8_t)((rbs[s] >> 11) & 1u);
                     r->grp = gidx; r->node = -1;
-                    o.linkR[s] = LINK_START | (uint32_t)(obase + n);
+                    mark_node(o.nbR, s);
                     n++;
                 }
         }
@@ -542,7 +543,7 @@ __device__ int rev_group(const FrameBits &F, const uint8_t *__restrict__ cls, co
                 r->startidx = -1;
                 r->flags = (uint8_t)((rbs[s] >> 11) & 1u);
                 r->grp = gidx; r->node = -1;
-                o.linkR[s] = LINK_START | (uint32_t)(obase + n);
+                mark_node(o.nbR, s);
             }
             n++;
         }
@@ -550,7 +551,7 @@ __device__ int rev_group(const FrameBits &F, const uint8_t *__restrict__ cls, co
     if (EMIT && n) {
         DGrp *g = &o.grp[gidx];
         g->stop = psk + 1; g->orf_begin = obase; g->n = n; g->node = -1; g->frame = -(F.f + 1); g->evkey = evkey;
-        o.linkR[psk] = LINK_STOP | (uint32_t)gidx;
+        mark_node(o.nbR, psk);
     }
     return n;
 }
@@ -587,8 +588,8 @@ __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
     OrfOut o;
     o.orf = EMIT ? b.orf + meta->orf_off : nullptr;
     o.grp = EMIT ? b.grp + meta->grp_off : nullptr;
-    o.linkF = b.linkF + off;
-    o.linkR = b.linkR + off;
+    o.nbF = (unsigned long long *)(b.nbits + meta->nbits_off);
+    o.nbR = o.nbF + 3 * (size_t)nw;
     const int nitems = 6 * nw;
     // count pass: one workgroup per contig (it needs the block scan); emit pass: the items are spread over
     // gridDim.y workgroups, every thread takes one item at a time (offsets are already known)
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(NT) void k_score(DBatch b) {
 
 // ------------------------------------------------------------------------------------------------
 // Nodes: one per ORF start and one per stop-group, sorted by position (then forward before reverse).
-// Also the coverage scan that finds the >500 bp uncovered runs of functions.py:320-334.
+// k_orf<true> has set one bit per node in two position bitmaps (forward-strand slot, reverse-strand slot); a node's
+// id is its rank = popcounts below it.  k_node_cov marks the bases covered by the longest ORF of every stop-group
+// in a third bitmap; k_node_rank turns the per-word popcounts into bases and finds the >500 bp uncovered runs of
+// functions.py:320-334; k_node_build lets every ORF / group write its own node; k_node_attr adds other_end and o1/o2.
 struct LinkInfo { int time; int val; bool stop; int idx; int far; };
 // time = when the reference wrote other_end[pos] for this slot (all ORFs of one group are added by one
 // event, so the group's evkey orders the writers); val = what it wrote last; far = index of the group's
@@ -813,7 +817,28 @@ __device__ __forceinline__ LinkInfo link_info(uint32_t link, const DOrf *orf, co
     return r;
 }
 
-__global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
+// coverage by the longest ORF of every stop-group (functions.py:321-330), 16 lanes per group, one atomicOr per word
+__global__ __launch_bounds__(NT) void k_node_cov(DBatch b) {
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0) return;
+    const int L = meta->L;
+    const DOrf *orf = b.orf + meta->orf_off;
+    const DGrp *grp = b.grp + meta->grp_off;
+    unsigned long long *cov = (unsigned long long *)(b.nbits + meta->nbits_off) + 6 * (size_t)meta->nw;
+    const int sub = threadIdx.x & 15;
+    for (int g = (int)blockIdx.y * (NT / 16) + ((int)threadIdx.x >> 4); g < meta->n_grp; g += (int)gridDim.y * (NT / 16)) {
+        const DGrp G = grp[g];
+        const DOrf *r = &orf[G.orf_begin + G.n - 1];
+        int mi = r->start < r->stop ? r->start : r->stop;
+        int ma = r->start > r->stop ? r->start : r->stop;
+        if (ma > L - 1) ma = L - 1;
+        if (ma <= mi) continue;
+        for (int w = (mi >> 6) + sub; w <= ((ma - 1) >> 6); w += 16) atomicOr(&cov[w], range_mask(w, mi, ma - 1)); // bases[n] = n for n in [mi, ma)
+    }
+}
+
+// per-word node-rank bases, and the bridge events (a covered base more than 500 after the previous covered base)
+__global__ __launch_bounds__(NT) void k_node_rank(DBatch b) {
     __shared__ uint32_t s_scan[NT / 64 + 1];
     DMeta *meta = &b.meta[blockIdx.x];
     const int tid = threadIdx.x;
@@ -821,72 +846,81 @@ __global__ __launch_bounds__(NT) void k_nodes(DBatch b) {
         if (tid == 0) { meta->n_node = 0; meta->n_edge = 0; }
         return;
     }
-    const int L = meta->L;
-    const int64_t off = meta->off;
-    DOrf *orf = b.orf + meta->orf_off;
-    DGrp *grp = b.grp + meta->grp_off;
-    const uint32_t *linkF = b.linkF + off, *linkR = b.linkR + off;
-    uint8_t *cov = b.cov + off;
-    int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off, *nother = b.nother + meta->node_off;
-    uint32_t *nlink = b.nlink + meta->node_off;
-    double *no = b.no + meta->node_off;
+    const int nwp = 3 * meta->nw;
+    const uint64_t *nbF = b.nbits + meta->nbits_off, *nbR = nbF + nwp, *cov = nbR + nwp;
+    uint32_t *nbase = b.nbase + meta->nbits_off / 3;
     if (tid == 0) meta->n_bridge = 0;
     __syncthreads();
-    // ordered sweep over positions: node ids, and "previous covered base" for the bridge test.
-    //    Every thread owns NPP consecutive positions per round; one sum-scan and one max-scan per NT*NPP positions.
-    constexpr int NPP = 8;
-    int run = 0;
-    uint32_t lastcov = 0;
-    for (int base = 0; base < L; base += NT * NPP) {
-        const int i0 = base + tid * NPP;
-        uint32_t lf[NPP], lr[NPP], cv[NPP];
-        uint32_t cnt = 0, lmax = 0;
-#pragma unroll
-        for (int j = 0; j < NPP; j++) {
-            const int i = i0 + j;
-            lf[j] = i < L ? linkF[i] : 0u;
-            lr[j] = i < L ? linkR[i] : 0u;
-            cv[j] = (i < L && cov[i]) ? (uint32_t)i : 0u;
-            cnt += (lf[j] ? 1u : 0u) + (lr[j] ? 1u : 0u);
-            lmax = cv[j] > lmax ? cv[j] : lmax;
-        }
-        uint32_t tot, mtot;
-        const uint32_t ex = block_excl_scan<NT>(cnt, s_scan, &tot);
-        uint32_t pm = block_excl_max<NT>(lmax, s_scan, &mtot);
-        if (pm < lastcov) pm = lastcov;
-        int id = run + (int)ex;
-#pragma unroll
-        for (int j = 0; j < NPP; j++) {
-            const int i = i0 + j;
-            if (cv[j]) {
-                if ((int)cv[j] - (int)pm > 500) { // functions.py:334
-                    const int k = atomicAdd(&meta->n_bridge, 1);
-                    if (k < PHX_MAX_BRIDGE) { meta->bridge[k].last = (int)pm; meta->bridge[k].base = (int)cv[j]; }
-                }
-                pm = cv[j];
-            }
-            if (lf[j]) {
-                npos[id] = i + 1; nlink[id] = lf[j];
-                ninfo[id] = NINFO(LINK_KIND(lf[j]) == LINK_START ? 0 : 1, i % 3 + 1);
-                if (LINK_KIND(lf[j]) == LINK_START) orf[LINK_IDX(lf[j])].node = id; else grp[LINK_IDX(lf[j])].node = id;
-                id++;
-            }
-            if (lr[j]) {
-                npos[id] = i + 1; nlink[id] = lr[j];
-                ninfo[id] = NINFO(LINK_KIND(lr[j]) == LINK_START ? 0 : 1, -(i % 3 + 1));
-                if (LINK_KIND(lr[j]) == LINK_START) orf[LINK_IDX(lr[j])].node = id; else grp[LINK_IDX(lr[j])].node = id;
-                id++;
-            }
-        }
-        run += (int)tot;
-        if (mtot > lastcov) lastcov = mtot;
+    const int per = (nwp + NT - 1) / NT;
+    const int a = tid * per, e = a + per < nwp ? a + per : nwp;
+    uint32_t cnt = 0, lastc = 0; // nodes in my words; last covered base in my words (0 = none; base 0 is never covered)
+    for (int w = a; w < e; w++) {
+        cnt += (uint32_t)(__popcll(nbF[w]) + __popcll(nbR[w]));
+        if (cov[w]) lastc = (uint32_t)(w * 64 + 63 - __clzll((long long)cov[w]));
     }
-    const double pgap = contig_pstop(meta->gc, L);
+    uint32_t tot, mtot;
+    uint32_t ex = block_excl_scan<NT>(cnt, s_scan, &tot);
+    uint32_t pm = block_excl_max<NT>(lastc, s_scan, &mtot);
+    for (int w = a; w < e; w++) {
+        nbase[w] = ex;
+        ex += (uint32_t)(__popcll(nbF[w]) + __popcll(nbR[w]));
+        if (cov[w]) {
+            const int first = w * 64 + __ffsll((long long)cov[w]) - 1;
+            if (first - (int)pm > 500) { // functions.py:334 (gaps inside one 64-base word cannot exceed 500)
+                const int k = atomicAdd(&meta->n_bridge, 1);
+                if (k < PHX_MAX_BRIDGE) { meta->bridge[k].last = (int)pm; meta->bridge[k].base = first; }
+            }
+            pm = (uint32_t)(w * 64 + 63 - __clzll((long long)cov[w]));
+        }
+    }
     if (tid == 0) {
-        npos[run] = 0; ninfo[run] = NINFO(2, 0); nlink[run] = 0; nother[run] = -1; no[run] = pgap;          // source, functions.py:440
-        npos[run + 1] = L + 1; ninfo[run + 1] = NINFO(3, 0); nlink[run + 1] = 0; nother[run + 1] = -1; no[run + 1] = pgap; // target
+        const int run = (int)tot, L = meta->L;
+        int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off, *nother = b.nother + meta->node_off;
+        uint32_t *nlink = b.nlink + meta->node_off;
+        double *no = b.no + meta->node_off;
+        const double pgap = contig_pstop(meta->gc, L);
         if (run + 2 != meta->n_node) meta->status = PHX_E_STATE; // n_node was sized as n_orf + n_grp + 2
-        if (meta->n_bridge > PHX_MAX_BRIDGE) meta->status = PHX_S_OVERFLOW;
+        else {
+            npos[run] = 0; ninfo[run] = NINFO(2, 0); nlink[run] = 0; nother[run] = -1; no[run] = pgap;                           // source, functions.py:440
+            npos[run + 1] = L + 1; ninfo[run + 1] = NINFO(3, 0); nlink[run + 1] = 0; nother[run + 1] = -1; no[run + 1] = pgap; // target
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && meta->n_bridge > PHX_MAX_BRIDGE) meta->status = PHX_S_OVERFLOW;
+}
+
+// node id of the node at 0-based key position q in the forward (rev = false) or reverse slot
+__device__ __forceinline__ int node_rank(const uint64_t *nbF, const uint64_t *nbR, const uint32_t *nbase, int q, bool rev) {
+    const int w = q >> 6;
+    const uint64_t below = (q & 63) ? (~0ull >> (64 - (q & 63))) : 0ull;
+    int id = (int)nbase[w] + __popcll(nbF[w] & below) + __popcll(nbR[w] & below);
+    if (rev) id += (int)((nbF[w] >> (q & 63)) & 1ull);
+    return id;
+}
+
+// every ORF writes its start node, every stop-group its stop node (functions.py:311-318)
+__global__ __launch_bounds__(NT) void k_node_build(DBatch b) {
+    DMeta *meta = &b.meta[blockIdx.x];
+    if (meta->status < 0 || meta->n_node <= 2) return;
+    const int nwp = 3 * meta->nw;
+    const uint64_t *nbF = b.nbits + meta->nbits_off, *nbR = nbF + nwp;
+    const uint32_t *nbase = b.nbase + meta->nbits_off / 3;
+    DOrf *orf = b.orf + meta->orf_off;
+    DGrp *grp = b.grp + meta->grp_off;
+    int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
+    uint32_t *nlink = b.nlink + meta->node_off;
+    const int gtid = (int)blockIdx.y * NT + (int)threadIdx.x, gstride = (int)gridDim.y * NT;
+    for (int k = gtid; k < meta->n_orf; k += gstride) {
+        DOrf *r = &orf[k];
+        const int id = node_rank(nbF, nbR, nbase, r->start - 1, r->frame < 0);
+        npos[id] = r->start; ninfo[id] = NINFO(0, r->frame); nlink[id] = LINK_START | (uint32_t)k;
+        r->node = id;
+    }
+    for (int g = gtid; g < meta->n_grp; g += gstride) {
+        DGrp *G = &grp[g];
+        const int id = node_rank(nbF, nbR, nbase, G->stop - 1, G->frame < 0);
+        npos[id] = G->stop; ninfo[id] = NINFO(1, G->frame); nlink[id] = LINK_STOP | (uint32_t)g;
+        G->node = id;
     }
 }
 
@@ -895,20 +929,21 @@ __global__ __launch_bounds__(NT) void k_node_attr(DBatch b) {
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0 || meta->n_node <= 2) return;
     const int L = meta->L;
-    const int64_t off = meta->off;
     const DOrf *orf = b.orf + meta->orf_off;
     const DGrp *grp = b.grp + meta->grp_off;
-    const uint32_t *linkF = b.linkF + off, *linkR = b.linkR + off;
     const int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
+    const uint32_t *nlink = b.nlink + meta->node_off;
     int32_t *nother = b.nother + meta->node_off;
     double *no = b.no + meta->node_off;
     const double pgap = contig_pstop(meta->gc, L);
     const int run = meta->n_node - 2;
     for (int v = (int)blockIdx.y * NT + (int)threadIdx.x; v < run; v += (int)gridDim.y * NT) {
-        const int q = npos[v] - 1;
         const int fr = NFRAME(ninfo[v]);
-        const uint32_t lmine = fr > 0 ? linkF[q] : linkR[q];
-        const uint32_t lother = fr > 0 ? linkR[q] : linkF[q];
+        const uint32_t lmine = nlink[v];
+        // the node of the other strand at the same position, if any, is my neighbour in the id order (forward first)
+        uint32_t lother = 0;
+        if (fr > 0) { if (v + 1 < run && npos[v + 1] == npos[v]) lother = nlink[v + 1]; }
+        else { if (v >= 1 && npos[v - 1] == npos[v]) lother = nlink[v - 1]; }
         LinkInfo a = link_info(lmine, orf, grp);
         int oe = a.val;
         double o = pgap;
@@ -931,25 +966,6 @@ __global__ __launch_bounds__(NT) void k_node_attr(DBatch b) {
         }
         nother[v] = oe;
         no[v] = o;
-    }
-}
-
-// coverage by the longest ORF of every stop-group (functions.py:321-330), 16 lanes per group
-__global__ __launch_bounds__(NT) void k_node_cov(DBatch b) {
-    DMeta *meta = &b.meta[blockIdx.x];
-    if (meta->status < 0) return;
-    const int L = meta->L;
-    const DOrf *orf = b.orf + meta->orf_off;
-    const DGrp *grp = b.grp + meta->grp_off;
-    uint8_t *cov = b.cov + meta->off;
-    const int sub = threadIdx.x & 15;
-    for (int g = (int)blockIdx.y * (NT / 16) + ((int)threadIdx.x >> 4); g < meta->n_grp; g += (int)gridDim.y * (NT / 16)) {
-        const DGrp G = grp[g];
-        const DOrf *r = &orf[G.orf_begin + G.n - 1];
-        int mi = r->start < r->stop ? r->start : r->stop;
-        int ma = r->start > r->stop ? r->start : r->stop;
-        if (ma > L - 1) ma = L - 1;
-        for (int n = mi + sub; n < ma; n += 16) cov[n] = 1;
     }
 }
 
@@ -1821,7 +1837,8 @@ void phxk_train(const DBatch *, void *) {}
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_nodes(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_nodes, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_count(const DBatch *b, void *stream) {
