@@ -74,7 +74,7 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_orf, b_grp, b_bits, b_item;
+    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot;
@@ -225,7 +225,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
     b->cls = (uint8_t *)c->b_cls.p;
     b->rbs = (uint16_t *)c->b_rbs.p;
-    b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p;
+    b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
     b->npos = (int32_t *)c->b_npos.p; b->ninfo = (int32_t *)c->b_ninfo.p; b->nother = (int32_t *)c->b_nother.p; b->parent = (int32_t *)c->b_parent.p;
@@ -391,7 +391,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot};
     for (DevBuf *b : all) release(*b);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -477,12 +477,15 @@ int phx_run(phx_ctx *c) {
         HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(c, hipStreamSynchronize(s));
-    int64_t o = 0, g = 0, v = 0;
+    int64_t o = 0, g = 0, v = 0, cb = 0;
     for (DMeta &m : c->meta) {
         m.orf_off = o; m.grp_off = g; m.node_off = v;
         m.n_node = m.status < 0 ? 0 : m.n_orf + m.n_grp + 2;
-        o += m.n_orf; g += m.n_grp; v += m.n_node;
+        m.cb_off = cb; m.ncw = m.n_node / 64 + 1;
+        o += m.n_orf; g += m.n_grp; v += m.n_node; cb += 2 * (int64_t)m.ncw;
     }
+    if ((rc = ensure(c, c->b_cbits, (size_t)(cb + 8) * 8))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->b_cbits.p, 0, (size_t)(cb + 8) * 8, s));
     c->tot_orf = o; c->tot_grp = g; c->tot_node = v;
     if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(o + 1)))) return rc;
     if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * (size_t)(g + 1)))) return rc;

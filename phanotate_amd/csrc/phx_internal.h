@@ -101,6 +101,9 @@ struct DMeta { // one per contig
     int32_t nw;            // bitmap words per (class, frame) = 8 * number of feature tiles
     int64_t bits_off;      // offset (in 64-bit words) of this contig's 12 bitmaps
     int64_t item_off;      // offset of this contig's 6*nw scan items
+    int64_t cb_off;        // offset (64-bit words) of this contig's close-node bitmaps
+    int32_t ncw;           // words per close-node bitmap = n_node/64 + 1
+    int32_t pad3;
     int64_t nbits_off;     // offset (64-bit words) of this contig's 9*nw node/coverage bitmap words; nbase offset = nbits_off/3
     int32_t n_orf_main, n_grp_main; // ORFs / groups emitted by the main loop (the end fragments follow)
     int32_t sssp_nl;   // 64-bit limbs this contig's path sums need (2, 4, 8 or 17)
@@ -131,6 +134,7 @@ struct DBatch {
     uint16_t *rbs;
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
+    uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); zeroed every run
     uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
     // per ORF / group

@@ -909,18 +909,21 @@ __global__ __launch_bounds__(NT) void k_node_build(DBatch b) {
     DGrp *grp = b.grp + meta->grp_off;
     int32_t *npos = b.npos + meta->node_off, *ninfo = b.ninfo + meta->node_off;
     uint32_t *nlink = b.nlink + meta->node_off;
+    unsigned long long *cF = (unsigned long long *)(b.cbits + meta->cb_off), *cR = cF + meta->ncw;
     const int gtid = (int)blockIdx.y * NT + (int)threadIdx.x, gstride = (int)gridDim.y * NT;
     for (int k = gtid; k < meta->n_orf; k += gstride) {
         DOrf *r = &orf[k];
         const int id = node_rank(nbF, nbR, nbase, r->start - 1, r->frame < 0);
         npos[id] = r->start; ninfo[id] = NINFO(0, r->frame); nlink[id] = LINK_START | (uint32_t)k;
         r->node = id;
+        if (r->frame < 0) atomicOr(&cR[id >> 6], 1ull << (id & 63)); // reverse start = close node
     }
     for (int g = gtid; g < meta->n_grp; g += gstride) {
         DGrp *G = &grp[g];
         const int id = node_rank(nbF, nbR, nbase, G->stop - 1, G->frame < 0);
         npos[id] = G->stop; ninfo[id] = NINFO(1, G->frame); nlink[id] = LINK_STOP | (uint32_t)g;
         G->node = id;
+        if (G->frame > 0) atomicOr(&cF[id >> 6], 1ull << (id & 63)); // forward stop = close node
     }
 }
 
@@ -1009,6 +1012,13 @@ __device__ __forceinline__ void emit_overlap(EdgeSink &s, int src, int length, b
     s.n++;
 }
 
+// Thread per destination node.  Every connector edge ends in an open node (forward start, reverse stop, target) and
+// starts in a close node (forward stop, reverse start) less than 500 bp away, so the candidates of a node are the set
+// bits of two node-id bitmaps (close nodes of either strand, written by k_node_build) inside an id range that the
+// position-rank structure gives in O(1):
+//   * left neighbours (gap edges, functions.py:401-405,417-419,427-433): EVERY close node in the range is an edge
+//     (one exception: forward start <- reverse start needs r-l > 2), so the count is a popcount;
+//   * right neighbours (overlap edges, functions.py:406-416,423-426,434-438): the other_end tests decide per candidate.
 template <bool FILL>
 __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
     DMeta *meta = &b.meta[blockIdx.x];
@@ -1021,6 +1031,10 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
     const uint32_t *nlink = b.nlink + meta->node_off;
     const double *no = b.no + meta->node_off;
     uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x; // V+1 entries per contig
+    const int nwp = 3 * meta->nw;
+    const uint64_t *nbF = b.nbits + meta->nbits_off, *nbR = nbF + nwp;
+    const uint32_t *nbase = b.nbase + meta->nbits_off / 3;
+    const uint64_t *cF = b.cbits + meta->cb_off, *cR = cF + meta->ncw; // close nodes by node id: forward stops / reverse starts
     const double pgap = contig_pstop(meta->gc, L);
     const int nbr = meta->n_bridge;
     bool parallel = false;
@@ -1038,124 +1052,121 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
         if (length > 300) return s_g100 + (double)length;
         return diff ? s_gap[length + 2] + 20.0 : s_gap[length + 2];
     };
-
-    // the node attributes of this block's 256 nodes and of 128 neighbours on either side are staged in LDS
-    // (a +-500 bp window holds ~30-60 nodes); scans that run past the staged range fall back to global memory
-    __shared__ int32_t s_pos[NT + 256], s_info[NT + 256], s_oth[NT + 256];
-    __shared__ double s_o[NT + 256];
+    // number of nodes whose 1-based position is < p1  (= id of the first node at position >= p1)
+    auto rank_lt = [&](int p1) -> int {
+        if (p1 <= 1) return 0;
+        if (p1 > L) return ncds;
+        return node_rank(nbF, nbR, nbase, p1 - 1, false);
+    };
     for (int base = (int)blockIdx.y * NT; base < V; base += (int)gridDim.y * NT) {
-        const int lo = base - 128 > 0 ? base - 128 : 0;
-        const int hi = base + NT + 128 < ncds ? base + NT + 128 : ncds;
-        const int nst = hi - lo;
-        __syncthreads();
-        for (int k = threadIdx.x; k < nst; k += NT) { s_pos[k] = npos[lo + k]; s_info[k] = ninfo[lo + k]; s_oth[k] = nother[lo + k]; s_o[k] = no[lo + k]; }
-        __syncthreads();
-        // Does every +-500 bp scan of this block stay inside the staged range?  (block-uniform; practically always)
-        const int vfirst = base < ncds ? base : ncds - 1, vlast = base + NT - 1 < ncds ? base + NT - 1 : ncds - 1;
-        const bool fits = nst > 0 && vfirst >= 0 && (lo == 0 || s_pos[vfirst - lo] - s_pos[0] >= 500) && (hi == ncds || s_pos[nst - 1] - s_pos[vlast - lo] >= 500);
-        auto node_edges = [&](auto POS, auto INFO, auto OTH, auto NO) {
         const int v = base + (int)threadIdx.x;
-            EdgeSink sink;
-            sink.n = 0;
-            sink.defer = b.defer_overlap != 0;
-            if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
-            if (v < V && v != SRC) {
-                if (v == TGT) {
-                    // functions.py:449-452
-                    for (int u = ncds - 1; u >= 0 && L - npos[u] <= 2000; u--) {
-                        const int t = NTYPE(ninfo[u]), f = NFRAME(ninfo[u]);
-                        if ((t == 0 && f < 0) || (t == 1 && f > 0)) emit_edge<FILL>(sink, u, gap(L - npos[u], false));
+        EdgeSink sink;
+        sink.n = 0;
+        sink.defer = b.defer_overlap != 0;
+        if (FILL && v < V) { sink.esrc = b.esrc + meta->edge_off + in_off[v]; sink.ew = b.ew + meta->edge_off + in_off[v]; }
+        if (v < V && v != SRC) {
+            if (v == TGT) {
+                // functions.py:449-452: every close node with L - pos <= 2000
+                const int a = rank_lt(L - 2000);
+                for (int w = a >> 6; w <= (ncds - 1) >> 6 && ncds > 0; w++) {
+                    uint64_t m = (cF[w] | cR[w]) & range_mask(w, a, ncds - 1);
+                    if (!FILL) sink.n += __popcll(m);
+                    else
+                        while (m) { const int u = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; emit_edge<FILL>(sink, u, gap(L - npos[u], false)); }
+                }
+            } else {
+                const int iv = ninfo[v];
+                const int t = NTYPE(iv), f = NFRAME(iv), pos = npos[v];
+                const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
+                if (!open) {
+                    // ORF edges, functions.py:311-318
+                    if (t == 1) { // forward stop: one edge per start of the group
+                        const DGrp G = grp[LINK_IDX(nlink[v])];
+                        if (!FILL) sink.n += G.n;
+                        else for (int k = 0; k < G.n; k++) emit_edge<FILL>(sink, orf[G.orf_begin + k].node, orf[G.orf_begin + k].weight);
+                    } else { // reverse start: from the group's stop node
+                        const DOrf *r = &orf[LINK_IDX(nlink[v])];
+                        emit_edge<FILL>(sink, FILL ? grp[r->grp].node : 0, FILL ? r->weight : 0.0);
                     }
                 } else {
-                    const int t = NTYPE(INFO(v)), f = NFRAME(INFO(v)), pos = POS(v);
-                    const bool open = (t == 0 && f > 0) || (t == 1 && f < 0);
-                    if (!open) {
-                        // ORF edges, functions.py:311-318
-                        if (t == 1) { // forward stop: one edge per start of the group
-                            const DGrp G = grp[LINK_IDX(nlink[v])];
-                            for (int k = 0; k < G.n; k++) emit_edge<FILL>(sink, orf[G.orf_begin + k].node, orf[G.orf_begin + k].weight);
-                        } else { // reverse start: from the group's stop node
-                            const DOrf *r = &orf[LINK_IDX(nlink[v])];
-                            emit_edge<FILL>(sink, grp[r->grp].node, r->weight);
-                        }
-                    } else {
-                        const int my_other = OTH(v);
-                        const double my_o = NO(v);
-                        if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
-                        // v as right node: gap edges l -> r (functions.py:401-405,417-419,427-433)
-                        for (int u = v - 1; u >= 0; u--) {
-                            const int d = pos - POS(u);
-                            if (d >= 500) break;
-                            if (d <= 0) continue;
-                            const int iu = INFO(u);
-                            const int lt = NTYPE(iu), lf = NFRAME(iu);
-                            if (t == 0) { // v = forward start
-                                if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
-                                else if (lt == 0 && lf < 0 && d > 2) emit_edge<FILL>(sink, u, gap(d - 3, true));
-                            } else { // v = reverse stop
-                                if (lt == 0 && lf < 0) emit_edge<FILL>(sink, u, gap(d - 3, false));
-                                else if (lt == 1 && lf > 0) emit_edge<FILL>(sink, u, gap(d - 3, true));
-                            }
-                        }
-                        // v as left node: overlap edges r -> l (functions.py:406-416,423-426,434-438)
-                        for (int u = v + 1; u < ncds; u++) {
-                            const int r = POS(u);
-                            const int d = r - pos;
-                            if (d >= 500) break;
-                            if (d <= 0) continue;
-                            const int iu = INFO(u);
-                            const int rt = NTYPE(iu), rf = NFRAME(iu);
-                            const int r_other = OTH(u);
-                            const double ps = (my_o + NO(u)) / 2.0; // ave([o1,o2]), functions.py:385
-                            if (t == 1) { // v = reverse stop (l), lf < 0
-                                if (rt == 0 && rf < 0) { // same strand: right is a reverse start
-                                    if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
-                                } else if (rt == 1 && rf > 0) { // right is a forward stop
-                                    if (r_other + 3 < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
-                                }
-                            } else { // v = forward start (l), lf > 0
-                                if (rt == 1 && rf > 0) { // same strand: right is a forward stop
-                                    if (f != rf && r < my_other && r_other < pos) emit_overlap<FILL>(sink, u, d + 3, false, ps);
-                                } else if (rt == 0 && rf < 0) { // right is a reverse start
-                                    if (r_other < pos && r < my_other) emit_overlap<FILL>(sink, u, d + 3, true, ps);
+                    if (pos <= 2000) emit_edge<FILL>(sink, SRC, gap(pos, false)); // functions.py:445-448
+                    // ---- v as right node: gap edges from every close node l with 0 < r-l < 500 ----
+                    {
+                        const int a = rank_lt(pos - 499), e = rank_lt(pos) - 1; // ids [a, e]
+                        // same strand as v: forward stop -> forward start, reverse start -> reverse stop; other strand: +20
+                        const uint64_t *same = t == 0 ? cF : cR, *diff = t == 0 ? cR : cF;
+                        for (int w = e >> 6; e >= a && w >= (a >> 6); w--) {
+                            const uint64_t rm = range_mask(w, a, e);
+                            uint64_t ms = same[w] & rm, md = diff[w] & rm;
+                            if (!FILL) {
+                                sink.n += __popcll(ms) + __popcll(md);
+                                if (t == 0) // forward start <- reverse start needs r-l > 2 (functions.py:431): look at the nearest ones only
+                                    while (md) { const int j = 63 - __clzll((long long)md); md &= ~(1ull << j); if (pos - npos[(w << 6) + j] > 2) break; sink.n--; }
+                            } else {
+                                uint64_t m = ms | md;
+                                while (m) { // descending ids = nearest first
+                                    const int j = 63 - __clzll((long long)m);
+                                    m &= ~(1ull << j);
+                                    const int u = (w << 6) + j;
+                                    const int d = pos - npos[u];
+                                    const bool isd = (md >> j) & 1ull;
+                                    if (isd && t == 0 && d <= 2) continue;
+                                    emit_edge<FILL>(sink, u, gap(d - 3, isd));
                                 }
                             }
                         }
-                        // long non-coding bridges, functions.py:334-354 (v as right node)
-                        for (int k = 0; k < nbr && k < PHX_MAX_BRIDGE; k++) {
-                            const int last = meta->bridge[k].last, bs = meta->bridge[k].base;
-                            if (!(bs - 1 <= pos && pos < bs + 500)) continue;
-                            // left nodes with last-500 < l <= last+1 : binary search the first pos > last-500
-                            int lo = 0, hi = ncds;
-                            while (lo < hi) { int m = (lo + hi) >> 1; if (npos[m] > last - 500) hi = m; else lo = m + 1; }
-                            for (int u = lo; u < ncds && npos[u] <= last + 1; u++) {
-                                const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
-                                const int d = pos - npos[u];
-                                bool hit = false, diff = false;
-                                if (t == 0) { // v forward start
-                                    if (lt == 1 && lf > 0) hit = true;
-                                    else if (lt == 0 && lf < 0) { hit = true; diff = true; }
-                                } else { // v reverse stop
-                                    if (lt == 0 && lf < 0) hit = true;
-                                    else if (lt == 1 && lf > 0) { hit = true; diff = true; }
+                    }
+                    // ---- v as left node: overlap edges from close nodes r with 0 < r-l < 500 that pass the other_end tests ----
+                    {
+                        const int my_other = nother[v];
+                        const double my_o = no[v];
+                        const int a = rank_lt(pos + 1), e = rank_lt(pos + 500) - 1; // ids [a, e]
+                        for (int w = a >> 6; e >= a && w <= (e >> 6); w++) {
+                            uint64_t m = (cF[w] | cR[w]) & range_mask(w, a, e);
+                            while (m) {
+                                const int j = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const int u = (w << 6) + j;
+                                const int r = npos[u], rf = NFRAME(ninfo[u]), r_other = nother[u];
+                                const int d = r - pos;
+                                bool hit, diff;
+                                if (t == 1) { // v = reverse stop (l), lf < 0
+                                    if (rf < 0) { hit = f != rf && r < my_other && r_other < pos; diff = false; }  // right is a reverse start
+                                    else { hit = r_other + 3 < pos && r < my_other; diff = true; }                 // right is a forward stop
+                                } else { // v = forward start (l), lf > 0
+                                    if (rf > 0) { hit = f != rf && r < my_other && r_other < pos; diff = false; }  // right is a forward stop
+                                    else { hit = r_other < pos && r < my_other; diff = true; }                     // right is a reverse start
                                 }
-                                if (hit) {
-                                    if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
-                                    emit_edge<FILL>(sink, u, gap(d - 3, diff));
-                                }
+                                if (hit) emit_overlap<FILL>(sink, u, d + 3, diff, (my_o + no[u]) / 2.0); // ave([o1,o2]), functions.py:385
+                            }
+                        }
+                    }
+                    // long non-coding bridges, functions.py:334-354 (v as right node)
+                    for (int k = 0; k < nbr && k < PHX_MAX_BRIDGE; k++) {
+                        const int last = meta->bridge[k].last, bs = meta->bridge[k].base;
+                        if (!(bs - 1 <= pos && pos < bs + 500)) continue;
+                        // left nodes with last-500 < l <= last+1
+                        for (int u = rank_lt(last - 499); u < ncds && npos[u] <= last + 1; u++) {
+                            const int lt = NTYPE(ninfo[u]), lf = NFRAME(ninfo[u]);
+                            const int d = pos - npos[u];
+                            bool hit = false, diff = false;
+                            if (t == 0) { // v forward start
+                                if (lt == 1 && lf > 0) hit = true;
+                                else if (lt == 0 && lf < 0) { hit = true; diff = true; }
+                            } else { // v reverse stop
+                                if (lt == 0 && lf < 0) hit = true;
+                                else if (lt == 1 && lf > 0) { hit = true; diff = true; }
+                            }
+                            if (hit) {
+                                if (d < 500) parallel = true; // the connect loop adds the same edge again: ValueError graphs.py:74
+                                emit_edge<FILL>(sink, u, gap(d - 3, diff));
                             }
                         }
                     }
                 }
             }
-            if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
-        };
-        if (fits)
-            node_edges([&](int u) -> int { return s_pos[u - lo]; }, [&](int u) -> int { return s_info[u - lo]; },
-                       [&](int u) -> int { return s_oth[u - lo]; }, [&](int u) -> double { return s_o[u - lo]; });
-        else
-            node_edges([&](int u) -> int { return npos[u]; }, [&](int u) -> int { return ninfo[u]; },
-                       [&](int u) -> int { return nother[u]; }, [&](int u) -> double { return no[u]; });
+        }
+        if (!FILL && v < V) in_off[v] = (uint32_t)sink.n; // in-degree; k_edges_scan turns it into an offset
     }
     if (parallel) atomicMin(&meta->status, PHX_S_PARALLEL);
 }
