@@ -1445,7 +1445,9 @@ __global__ void k_path(DBatch b) {
 // once at the end (lowest-index tight in-edge), which is also what makes ties schedule-independent.
 #define SW_ADV 32
 #define SW_MAX 64
+#ifndef SW_ECAP
 #define SW_ECAP 1024
+#endif
 #ifndef SW_LPN
 #define SW_LPN 8 // lanes per node (4, 8 or 16; a DPP row has 16 lanes)
 #endif
@@ -1489,7 +1491,7 @@ template <int NL>
 __device__ __forceinline__ WInt<NL> wi_row_min(WInt<NL> x, int sub) {
     WInt<NL> y;
     y = wi_min_bf<NL>(x, wi_row_shr<1, NL>(x)); if (sub >= 1) x = y;
-    y = wi_min_bf<NL>(x, wi_row_shr<2, NL>(x)); if (sub >= 2) x = y;
+    if (SW_LPN > 2) { y = wi_min_bf<NL>(x, wi_row_shr<2, NL>(x)); if (sub >= 2) x = y; }
     if (SW_LPN > 4) { y = wi_min_bf<NL>(x, wi_row_shr<4, NL>(x)); if (sub >= 4) x = y; }
     if (SW_LPN > 8) { y = wi_min_bf<NL>(x, wi_row_shr<8, NL>(x)); if (sub >= 8) x = y; }
     return x;
@@ -1497,7 +1499,7 @@ __device__ __forceinline__ WInt<NL> wi_row_min(WInt<NL> x, int sub) {
 __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
     uint32_t o;
     o = dpp_row_shr<1>(x); if (sub >= 1 && o < x) x = o;
-    o = dpp_row_shr<2>(x); if (sub >= 2 && o < x) x = o;
+    if (SW_LPN > 2) { o = dpp_row_shr<2>(x); if (sub >= 2 && o < x) x = o; }
     if (SW_LPN > 4) { o = dpp_row_shr<4>(x); if (sub >= 4 && o < x) x = o; }
     if (SW_LPN > 8) { o = dpp_row_shr<8>(x); if (sub >= 8 && o < x) x = o; }
     return x;
@@ -1511,7 +1513,9 @@ __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
 // Window k starts at node 32k; its size (32 + look-ahead, <= 64) is planned once per contig.  While window k
 // iterates out of LDS, the in-edge tile, the node types, the ring fill-in and the in-edge offsets of window
 // k+1 are already in flight into registers, so global-memory latency stays off the critical path.
+#ifndef SW_RING
 #define SW_RING 1024
+#endif
 #define SW_EPT ((SW_ECAP + SW_THREADS - 1) / SW_THREADS) // tile edges prefetched per thread
 #ifndef SW_RC
 #define SW_RC 1 // in-edges per lane and node kept in registers

@@ -473,3 +473,17 @@ def test_fuzz_small_random_contigs(pa, oracle):
             check_contig(ann, i, s, o, genes, st if st != 1 else 0)
     assert nbad >= 5
     ann.close()
+
+
+def test_large_contig_beyond_lds_parent_table(pa, oracle):
+    """A 400 kb contig (~22 k nodes): more nodes than the LDS parent table of the SSSP kernel holds (the final walk then
+    chases parent edges in global memory), 260 feature tiles, 2000 bitmap words per frame.  Everything must still
+    equal the oracle."""
+    seq = pa.synth_contig(31337, 400000)
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    o = oracle.run(seq)
+    assert status == 0 and o["status"] == 0
+    assert ann.globals(0).n_node > 12000
+    check_contig(ann, 0, seq, o, genes, status)
+    ann.close()
