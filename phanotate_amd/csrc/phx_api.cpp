@@ -102,10 +102,11 @@ namespace {
     } while (0)
 
 int ensure(phx_ctx *c, DevBuf &b, size_t bytes) {
-    if (bytes <= b.cap && b.p) return PHX_OK;
+    // 2 KB of slack behind every array: the staging loads of k_sssp_wave read whole 16-byte / 256-node groups
+    if (bytes + 2048 <= b.cap && b.p) return PHX_OK;
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
+    size_t want = bytes + bytes / 8 + 4096;
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
     return PHX_OK;
@@ -439,6 +440,8 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
     return PHX_OK;
 }
 
+static double host_contig_pstop(uint32_t gc, int L);
+
 int phx_run(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (!c->uploaded) return PHX_E_STATE;
@@ -519,20 +522,40 @@ int phx_run(phx_ctx *c) {
     int nlmax = 2;
     struct Cls { bool any = false; size_t lds = 0; } cls[4][3]; // [limb class][mode]
     const int nl_of[4] = {2, 4, 8, 17};
+    const bool no_wave = getenv("PHX_SSSP_NOWAVE") != nullptr; // test hook: keep every contig off the wavefront kernel
     for (DMeta &m : c->meta) {
         m.edge_off = e;
-        m.sssp_nl = 2; m.sssp_mode = 0;
+        m.sssp_nl = 2; m.sssp_mode = 0; m.sssp_fb = 0;
         if (m.status < 0) { m.n_edge = 0; continue; }
         e += m.n_edge;
-        // |dist| <= V * max|w|: bits = maxexp + ceil(log2 V) + sign + one spare bit below the INF pattern
-        const int bits = std::max(m.maxexp, 64) + (int)std::ceil(std::log2((double)std::max(m.n_node, 2))) + 3;
+        // A tentative distance is the length of a walk that uses every ORF edge at most once (a shortest path is simple;
+        // longer walks never win), so |dist| <= B = sum |w_orf| + (V/2) * max |w_connector|.  The connector bound follows
+        // functions.py:26-46: overlap < 500 bp, gap <= 300 bp or bridge pow(.)+length; terminals are smaller still.
+        // A candidate d(u)+w needs one more bit, the sign another, and the "unreached" pattern sits two bits higher;
+        // one bit covers the rounding of the fp64 sum.
+        int bits = 4096;
+        if (m.maxexp < 2000) {
+            const double pst = host_contig_pstop(m.gc, (int)m.L);
+            const double cmax = std::max(std::max(1.0 / std::pow(1.0 - pst, 500.0), 1.0 / std::pow(1.0 - pst, 100.0)) + 20.0, (double)m.L + 21.0) * 1000.0;
+            const double bound = m.wsum + 0.5 * (double)std::max(m.n_node, 2) * cmax;
+            int eb = 0;
+            (void)std::frexp(bound, &eb);
+            bits = std::max(eb, m.maxexp) + 5;
+        }
         int k = bits <= 128 ? 0 : bits <= 256 ? 1 : bits <= 512 ? 2 : 3;
+        if (getenv("PHX_DEBUG_BITS")) fprintf(stderr, "bits %d maxexp %d V %d\n", bits, m.maxexp, m.n_node);
         if (bits > 17 * 64) { m.status = PHX_S_OVERFLOW; continue; }
         m.sssp_nl = nl_of[k];
         nlmax = std::max(nlmax, m.sssp_nl);
         const size_t lds = phxk_sssp_lds_bytes(m.n_node, m.sssp_nl);
-        m.sssp_mode = c->force_global_sssp ? 0 : lds <= 158 * 1024 ? 1 : 0;
-        if (m.n_node > 2) { cls[k][m.sssp_mode].any = true; cls[k][m.sssp_mode].lds = std::max(cls[k][m.sssp_mode].lds, lds); }
+        // the kernel a contig falls back to when the wavefront kernel hands it back (and the one it gets otherwise)
+        m.sssp_fb = c->force_global_sssp ? 0 : lds <= 158 * 1024 ? 1 : 0;
+        m.sssp_mode = (!c->force_global_sssp && !no_wave && phxk_sssp_wave_ok(m.sssp_nl)) ? 2 : m.sssp_fb;
+        if (m.n_node > 2) {
+            cls[k][m.sssp_mode].any = true;
+            if (m.sssp_mode == 2) cls[k][m.sssp_fb].any = true; // launched after the wavefront kernel, on the same stream
+            if (m.sssp_fb == 1) cls[k][1].lds = std::max(cls[k][1].lds, lds);
+        }
     }
     c->tot_edge = e;
     c->n_limbs = nlmax;
@@ -558,20 +581,21 @@ int phx_run(phx_ctx *c) {
         int nlaunch = 0;
         bool used[3] = {false, false, false};
         int nclass = 0;
-        for (int k = 0; k < 4; k++) for (int mode = 0; mode < 3; mode++) nclass += cls[k][mode].any ? 1 : 0;
+        for (int k = 0; k < 4; k++) nclass += (cls[k][0].any || cls[k][1].any || cls[k][2].any) ? 1 : 0;
         if (nclass > 1 && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
-        for (int k = 3; k >= 0; k--) // widest integers first: fewest contigs, longest per-contig time
+        for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
+            if (!cls[k][0].any && !cls[k][1].any && !cls[k][2].any) continue;
+            hipStream_t st = s;
+            if (nlaunch > 0 && c->aux[0]) {
+                const int a = (nlaunch - 1) % 3;
+                if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
+                st = c->aux[a];
+            }
+            // one stream per limb class; within it the wavefront kernel first, then the kernels it may hand contigs to
             for (int mode = 2; mode >= 0; mode--)
-                if (cls[k][mode].any) {
-                    hipStream_t st = s;
-                    if (nlaunch > 0 && c->aux[0]) {
-                        const int a = (nlaunch - 1) % 3;
-                        if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
-                        st = c->aux[a];
-                    }
-                    phxk_sssp(&b, nl_of[k], mode, cls[k][mode].lds, st);
-                    nlaunch++;
-                }
+                if (cls[k][mode].any) phxk_sssp(&b, nl_of[k], mode, cls[k][mode].lds, st);
+            nlaunch++;
+        }
         for (int a = 0; a < 3; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
     }
@@ -583,6 +607,27 @@ int phx_run(phx_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
+    if (getenv("PHX_DEBUG_WAVE")) {
+        int nfb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nw = 0;
+        for (int i = 0; i < n; i++) { if (c->meta[i].sssp_mode == 2) nw++; else if (c->meta[i].n_node > 2 && c->meta[i].sssp_nl == 2) nfb[c->meta[i].pad2 & 7]++; }
+        fprintf(stderr, "wave kernel: %d contigs done, handed back: plan %d spill %d no-convergence %d rollbacks %d other %d\n", nw, nfb[1], nfb[2], nfb[3], nfb[4], nfb[0]);
+        std::vector<std::pair<double, int>> tt;
+        long nroll = 0;
+        for (int i = 0; i < n; i++) if (c->meta[i].sssp_mode == 2) { const DMeta &m = c->meta[i]; tt.push_back({(m.pmax[0] + m.pmax[1] + m.pmax[2] + m.pmax[3] + m.pmin[0] + m.pmin[1]) * 0.01, i}); nroll += m.sweeps - 1; }
+        std::sort(tt.begin(), tt.end());
+        if (!tt.empty()) {
+            const DMeta &m = c->meta[tt.back().second];
+            fprintf(stderr, "wave kernel (WV_PROFILE builds): per-contig us p50 %.0f p90 %.0f p99 %.0f max %.0f; rollbacks %ld; slowest contig %d: V=%d phases=%d sweeps=%d | dma-wait %.1f classes+setup %.1f gather %.1f plan+stage %.1f phases %.1f end+rest %.1f\n",
+                    tt[tt.size() / 2].first, tt[tt.size() * 9 / 10].first, tt[tt.size() * 99 / 100].first, tt.back().first, nroll, tt.back().second, m.n_node, m.sssp_iters, m.sweeps,
+                    m.pmax[0] * 0.01, m.pmax[1] * 0.01, m.pmax[2] * 0.01, m.pmax[3] * 0.01, m.pmin[0] * 0.01, m.pmin[1] * 0.01);
+            const DMeta &q = c->meta[tt[tt.size() / 2].second];
+            fprintf(stderr, "  median contig %d: phases %d: relax %.1f followers %.1f spill %.1f apply %.1f loop %.1f us | setup %.1f gather %.1f plan %.1f end %.1f\n", tt[tt.size() / 2].second, q.sssp_iters,
+                    q.bg[0] * 0.01, q.bg[1] * 0.01, q.bg[2] * 0.01, q.bg[3] * 0.01, q.bg[4] * 0.01, q.pmax[1] * 0.01, q.pmax[2] * 0.01, q.pmax[3] * 0.01, q.pmin[1] * 0.01);
+        }
+    }
+    if (getenv("PHX_DEBUG_WAVE"))
+        for (int i = 0; i < n && i < 4; i++) fprintf(stderr, "wave contig %d: V=%d phases=%d sweeps=%d | dma-wait %.1f classes+setup %.1f gather %.1f plan+stage %.1f phases %.1f end+rest %.1f us\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps,
+                c->meta[i].pmax[0] * 0.01, c->meta[i].pmax[1] * 0.01, c->meta[i].pmax[2] * 0.01, c->meta[i].pmax[3] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pmin[1] * 0.01);
     if (getenv("PHX_DEBUG_SSSP"))
         for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pad2 * 0.01);
     c->ran = true;

@@ -103,13 +103,14 @@ struct DMeta { // one per contig
     int64_t item_off;      // offset of this contig's 6*nw scan items
     int64_t cb_off;        // offset (64-bit words) of this contig's close-node bitmaps
     int32_t ncw;           // words per close-node bitmap = n_node/64 + 1
-    int32_t pad3;
+    int32_t sssp_fb;       // kernel (0 / 1) that takes the contig over if the wavefront kernel (mode 2) hands it back
     int64_t nbits_off;     // offset (64-bit words) of this contig's 9*nw node/coverage bitmap words; nbase offset = nbits_off/3
     int32_t n_orf_main, n_grp_main; // ORFs / groups emitted by the main loop (the end fragments follow)
     int32_t sssp_nl;   // 64-bit limbs this contig's path sums need (2, 4, 8 or 17)
     int32_t sssp_iters;
     int32_t pad2;
-    int32_t sssp_mode; // 0 = global-memory kernel, 1 = LDS kernel (<= 64 KB), 2 = LDS kernel (<= 160 KB)
+    int32_t sssp_mode; // 0 = global-memory kernel, 1 = workgroup-per-contig LDS kernel, 2 = wavefront-per-contig kernel
+    double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
 };
 
 struct DTile {
@@ -171,6 +172,7 @@ void phxk_nodes(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
+int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 #ifdef __cplusplus
 }

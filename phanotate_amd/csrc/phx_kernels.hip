@@ -16,6 +16,7 @@
 // No MFMA anywhere: the path has no dense contraction.  All integer outputs are
 // bit-exact with the reference; fp64 is used where the reference uses Decimal (edge weights only).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "phx_internal.h"
 
@@ -757,9 +758,10 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
 // hold = prod ((1-pstop)^pos_max[imax])^pos_min[imin] = (1-pstop)^S ; weight = -(1/hold)*w_start*w_rbs
 __global__ __launch_bounds__(NT) void k_score(DBatch b) {
     __shared__ int s_maxexp;
+    __shared__ double s_wsum;
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
-    if (threadIdx.x == 0) s_maxexp = 0;
+    if (threadIdx.x == 0) { s_maxexp = 0; s_wsum = 0.0; }
     __syncthreads();
     DOrf *orf = b.orf + meta->orf_off;
     const DParams *P = b.params;
@@ -777,6 +779,7 @@ __global__ __launch_bounds__(NT) void k_score(DBatch b) {
         for (int i = 0; i < 4; i++) { pmax[i] /= ymx; pmin[i] /= ymn; }
     }
     int mymax = 0;
+    double mysum = 0.0;
     for (int k = threadIdx.x; k < meta->n_orf; k += NT) {
         DOrf *r = &orf[k];
         double S = 0;
@@ -793,10 +796,11 @@ __global__ __launch_bounds__(NT) void k_score(DBatch b) {
         frexp(s * 1000.0, &e);
         if (!(s < 1.0e300)) e = 4096; // inf / nan: force the overflow status
         mymax = e > mymax ? e : mymax;
+        if (s < 1.0e300) mysum += s * 1000.0;
     }
-    if (mymax) atomicMax(&s_maxexp, mymax);
+    if (mymax) { atomicMax(&s_maxexp, mymax); atomicAdd(&s_wsum, mysum); }
     __syncthreads();
-    if (threadIdx.x == 0) meta->maxexp = s_maxexp;
+    if (threadIdx.x == 0) { meta->maxexp = s_maxexp; meta->wsum = s_wsum; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1517,8 +1521,11 @@ __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
 #define SW_RING 1024
 #endif
 #define SW_EPT ((SW_ECAP + SW_THREADS - 1) / SW_THREADS) // tile edges prefetched per thread
-#ifndef SW_RC
-#define SW_RC 1 // in-edges per lane and node kept in registers
+#ifndef SW_RCA
+#define SW_RCA 1 // in-edges per lane of a close node kept in registers
+#endif
+#ifndef SW_RCB
+#define SW_RCB 1 // in-edges per lane of an open node kept in registers
 #endif
 #ifndef SW_WPS
 #define SW_WPS 6 // wavefronts per SIMD the register allocation must allow (workgroups/CU = SW_WPS * 256 / SW_THREADS)
@@ -1686,21 +1693,29 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
             const int iaB = actB ? (int)(s_off[cur][lB] - e0) + sub : 0, ibB = actB ? (int)(s_off[cur][lB + 1] - e0) : 0;
             uint64_t *slotA = ring + (size_t)((v0 + lA) & (SW_RING - 1)) * NL, *slotB = ring + (size_t)((v0 + lB) & (SW_RING - 1)) * NL;
             uint64_t *gA = gdist + (size_t)(v0 + lA) * NL, *gB = gdist + (size_t)(v0 + lB) * NL;
-            // the first SW_RC in-edges of this lane stay in registers for all rounds of the window
-            uint32_t csA[SW_RC], csB[SW_RC];
-            WInt<NL> cwA[SW_RC], cwB[SW_RC];
-#pragma unroll
-            for (int j = 0; j < SW_RC; j++) {
+            // the first SW_RCA / SW_RCB in-edges of this lane stay in registers for all rounds of the window
+            // (close nodes have 1-2 in-edges — the starts of one stop-group; open nodes ~14 — the connectors)
+            uint32_t csA[SW_RCA], csB[SW_RCB];
+            WInt<NL> cwA[SW_RCA], cwB[SW_RCB];
+            {
                 WInt<NL> big;
 #pragma unroll
                 for (int i = 0; i < NL; i++) big.v[i] = 0;
                 big.v[NL - 1] = WBIG_TOP;
-                const int ia = iaA + j * SW_LPN, ib = iaB + j * SW_LPN;
-                const bool oa = tiled && ia < ibA, ob = tiled && ib < ibB;
-                csA[j] = oa ? tsrc[ia] : (uint32_t)SW_RING;
-                cwA[j] = oa ? wi_load<NL>(tw + (size_t)ia * NL) : big;
-                csB[j] = ob ? tsrc[ib] : (uint32_t)SW_RING;
-                cwB[j] = ob ? wi_load<NL>(tw + (size_t)ib * NL) : big;
+#pragma unroll
+                for (int j = 0; j < SW_RCA; j++) {
+                    const int ia = iaA + j * SW_LPN;
+                    const bool oa = tiled && ia < ibA;
+                    csA[j] = oa ? tsrc[ia] : (uint32_t)SW_RING;
+                    cwA[j] = oa ? wi_load<NL>(tw + (size_t)ia * NL) : big;
+                }
+#pragma unroll
+                for (int j = 0; j < SW_RCB; j++) {
+                    const int ib = iaB + j * SW_LPN;
+                    const bool ob = tiled && ib < ibB;
+                    csB[j] = ob ? tsrc[ib] : (uint32_t)SW_RING;
+                    cwB[j] = ob ? wi_load<NL>(tw + (size_t)ib * NL) : big;
+                }
             }
             // A phase that changes nothing ends the window: the next phase would read exactly what it read last time.
             // (Exception: the window's very first phase A — phase B has not seen this window's close nodes yet.)
@@ -1719,11 +1734,25 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
                     if (act) d0 = wi_load<NL>(myslot);
                     WInt<NL> best = d0;
                     if (tiled) {
+                        int i;
+                        if (ph) {
 #pragma unroll
-                        for (int j = 0; j < SW_RC; j++)
-                            best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)(ph ? csB[j] : csA[j]) * NL), ph ? cwB[j] : cwA[j]));
-                        for (int i = ia + SW_RC * SW_LPN; i < ib; i += SW_LPN)
-                            best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)tsrc[i] * NL), wi_load<NL>(tw + (size_t)i * NL)));
+                            for (int j = 0; j < SW_RCB; j++) best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)csB[j] * NL), cwB[j]));
+                            i = ia + SW_RCB * SW_LPN;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < SW_RCA; j++) best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)csA[j] * NL), cwA[j]));
+                            i = ia + SW_RCA * SW_LPN;
+                        }
+                        // the rare rest comes from the LDS tile; the source slot of the next edge is already on its way
+                        uint32_t sl = i < ib ? tsrc[i] : 0u;
+                        while (i < ib) {
+                            const int in = i + SW_LPN;
+                            const uint32_t sn = in < ib ? tsrc[in] : 0u;
+                            best = wi_min_bf<NL>(best, wi_add<NL>(wi_load<NL>(ring + (size_t)sl * NL), wi_load<NL>(tw + (size_t)i * NL)));
+                            sl = sn;
+                            i = in;
+                        }
                     } else {
                         for (int i = ia; i < ib; i += SW_LPN) {
                             const uint32_t u = esrc[e0 + i];
@@ -1839,6 +1868,8 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
     }
 }
 
+#include "phx_sssp_wave.inc"
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 extern "C" {
@@ -1882,10 +1913,19 @@ size_t phxk_sssp_lds_bytes(int V, int nl) {
     return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + (size_t)(V / SW_ADV + 1) + 64;
 }
 
-// mode 0: global-memory kernel (+ k_path); mode 1/2: LDS kernel with `lds_bytes` of dynamic LDS
+int phxk_sssp_wave_ok(int nl) { return nl == 2; }
+
+// mode 0: global-memory kernel (+ k_path); mode 1: workgroup-per-contig LDS kernel with `lds_bytes` of dynamic LDS;
+// mode 2: wavefront-per-contig kernel (contigs it hands back carry their fallback mode in sssp_mode afterwards)
 void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream) {
     dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
+    if (mode == 2) {
+        const size_t lb = wv_lds_bytes<2>();
+        (void)hipFuncSetAttribute((const void *)k_sssp_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+        hipLaunchKernelGGL(k_sssp_wave<2>, g, dim3(64), lb, s, *b);
+        return;
+    }
     if (mode == 0) {
         dim3 gp((b->n_contig + 63) / 64), tp(64);
         switch (nl) {
