@@ -119,6 +119,8 @@ typedef struct phx_globals {
     int32_t sssp_sweeps; /* outer sweeps of the device relaxation */
     int32_t sssp_iters;  /* relaxation rounds summed over all windows and sweeps */
     int32_t status;
+    int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig */
+    int32_t sssp_handed_back; /* 1: the wavefront kernel passed the contig on (spill list / window limits) */
 } phx_globals;
 
 /* ---- library ---- */

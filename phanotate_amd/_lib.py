@@ -36,6 +36,7 @@ class Globals(C.Structure):
         ("pos_max", C.c_double * 4), ("pos_min", C.c_double * 4),
         ("n_orf", C.c_int32), ("n_group", C.c_int32), ("n_node", C.c_int32), ("n_edge", C.c_int32), ("n_bridge", C.c_int32),
         ("n_limbs", C.c_int32), ("sssp_sweeps", C.c_int32), ("sssp_iters", C.c_int32), ("status", C.c_int32),
+        ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32),
     ]
 
 

@@ -609,7 +609,7 @@ int phx_run(phx_ctx *c) {
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_WAVE")) {
         int nfb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nw = 0;
-        for (int i = 0; i < n; i++) { if (c->meta[i].sssp_mode == 2) nw++; else if (c->meta[i].n_node > 2 && c->meta[i].sssp_nl == 2) nfb[c->meta[i].pad2 & 7]++; }
+        for (int i = 0; i < n; i++) { if (c->meta[i].sssp_mode == 2) nw++; else if (c->meta[i].n_node > 2 && c->meta[i].sssp_nl == 2) nfb[c->meta[i].sssp_why & 7]++; }
         fprintf(stderr, "wave kernel: %d contigs done, handed back: plan %d spill %d no-convergence %d rollbacks %d other %d\n", nw, nfb[1], nfb[2], nfb[3], nfb[4], nfb[0]);
         std::vector<std::pair<double, int>> tt;
         long nroll = 0;
@@ -629,7 +629,7 @@ int phx_run(phx_ctx *c) {
         for (int i = 0; i < n && i < 4; i++) fprintf(stderr, "wave contig %d: V=%d phases=%d sweeps=%d | dma-wait %.1f classes+setup %.1f gather %.1f plan+stage %.1f phases %.1f end+rest %.1f us\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps,
                 c->meta[i].pmax[0] * 0.01, c->meta[i].pmax[1] * 0.01, c->meta[i].pmax[2] * 0.01, c->meta[i].pmax[3] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pmin[1] * 0.01);
     if (getenv("PHX_DEBUG_SSSP"))
-        for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pad2 * 0.01);
+        for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].sssp_why * 0.01);
     c->ran = true;
     return PHX_OK;
 }
@@ -714,6 +714,8 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->n_orf = m.n_orf; out->n_group = m.n_grp; out->n_node = m.n_node; out->n_edge = m.n_edge; out->n_bridge = m.n_bridge;
     out->sssp_sweeps = m.sweeps;
     out->sssp_iters = m.sssp_iters;
+    out->sssp_kernel = m.sssp_mode;
+    out->sssp_handed_back = m.sssp_why > 0 ? 1 : 0;
     return PHX_OK;
 }
 

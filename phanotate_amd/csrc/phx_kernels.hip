@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
         atomicSub(b.gene_total + 1, 1u);
 #endif
 #ifdef SW_PROFILE
-        { long long t = wall_clock64(); meta->pmax[0] = (uint32_t)t_setup; meta->pmin[0] = (uint32_t)t_iter; meta->pad2 = (int32_t)(t - t_mark); }
+        { long long t = wall_clock64(); meta->pmax[0] = (uint32_t)t_setup; meta->pmin[0] = (uint32_t)t_iter; meta->sssp_why = (int32_t)(t - t_mark); }
 #endif
     }
     __syncthreads();

@@ -487,3 +487,38 @@ def test_large_contig_beyond_lds_parent_table(pa, oracle):
     assert ann.globals(0).n_node > 12000
     check_contig(ann, 0, seq, o, genes, status)
     ann.close()
+
+
+@pytest.mark.parametrize("ncodons,p_gtg,expect", [(3000, 0.12, "wave"), (3500, 0.20, "wave"), (4000, 0.45, "handed_back")])
+def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, expect):
+    """A 9-12 kb reading frame in a GC-rich contig: p_stop is small, so the path sums still fit 128 bits and the contig
+    goes to the wavefront-per-contig kernel.  The ORF's start nodes lie further back than its LDS distance ring holds
+    (sources folded in from global memory), and its stop node has hundreds of in-edges (one per in-frame gtg): more than
+    a wavefront's lanes (helper lanes + spill list) and, in the last case, more than the spill list takes, so that the
+    contig is handed to the workgroup kernel.  Genes must equal the exact solution of the oracle's graph either way."""
+    rng = np.random.RandomState(7)
+    def gc_rich(n):
+        return "".join(rng.choice(list("acgt"), n, p=[0.1, 0.4, 0.4, 0.1]))
+    sense = [a + b + c for a in "cg" for b in "acgt" for c in "cg"]  # no stop codon starts with c/g... and none ends in c/g
+    sense = [c for c in sense if c != "gtg"]
+    body = "".join("gtg" if rng.rand() < p_gtg else sense[rng.randint(len(sense))] for _ in range(ncodons))
+    seq = gc_rich(6000) + "atg" + body + "taa" + gc_rich(6000)
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    gl = ann.globals(0)
+    assert status == 0
+    assert gl.n_limbs == 2
+    o = oracle.run(seq, stages=2)
+    assert o["status"] == 0
+    deg = np.bincount(o["edge_dst"])
+    assert deg.max() > 64 * 4  # the stop node needs more than 64 lanes of 4 in-edges
+    if expect == "wave":
+        assert gl.sssp_kernel == 2 and gl.sssp_handed_back == 0
+    else:
+        assert deg.max() > 64 * 4 + 512  # ... and more than the spill list holds
+        assert gl.sssp_kernel == 1 and gl.sssp_handed_back == 1
+    dist, want = _py_bellman_ford_genes(o)
+    assert [(int(g["left"]), int(g["right"])) for g in genes] == want
+    p, d = ann.path(0)
+    assert abs(d - dist) <= abs(dist) * 1e-12
+    ann.close()
