@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--contigs", type=int, default=1000, help="contigs per GPU (BASELINE config 4: 1000 x 50 kb on 1 GPU)")
     ap.add_argument("--length", type=int, default=50000)
-    ap.add_argument("--cpu-contigs", type=int, default=64, help="size of the bounded sample timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-contigs", type=int, default=256, help="size of the bounded sample timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
