@@ -77,7 +77,12 @@ struct phx_ctx {
     DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
-    DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot;
+    DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
+    DTotals *h_tot = nullptr; // pinned
+    bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
+    int last_mask = 0;
+    int64_t last_lds[4] = {0, 0, 0, 0};
+    int64_t max_len = 0;
     void *h_stage = nullptr; // pinned staging for H2D of ASCII
     size_t h_stage_cap = 0;
     std::vector<DGene> h_genes;
@@ -217,10 +222,34 @@ void collect_timers(phx_ctx *c) {
     c->pending.clear();
 }
 
+// elements the context's buffers can take (every buffer keeps 2 KB of slack, see ensure())
+int64_t cap_of(const DevBuf &b, size_t elem, int64_t reserve) {
+    if (!b.p || b.cap < 2048 + elem) return 0;
+    const int64_t k = (int64_t)((b.cap - 2048) / elem) - reserve;
+    return k > 0 ? k : 0;
+}
+void current_caps(const phx_ctx *c, DCaps *k) {
+    const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
+    k->orf = cap_of(c->b_orf, sizeof(DOrf), 1);
+    k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, sizeof(DGene), 1));
+    int64_t v = cap_of(c->b_npos, 4, 8);
+    for (const DevBuf *q : {&c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_path}) v = std::min(v, cap_of(*q, 4, 8));
+    v = std::min(v, cap_of(c->b_no, 8, 8));
+    v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
+    v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
+    k->node = v;
+    k->cb = cap_of(c->b_cbits, 8, 8);
+    k->edge = std::min(cap_of(c->b_esrc, 4, 1), cap_of(c->b_ew, 8, 1));
+    k->limbs = limbs;
+    k->flags = (c->force_global_sssp ? 1 : 0) | (getenv("PHX_SSSP_NOWAVE") ? 2 : 0);
+}
+
 void fill_batch(phx_ctx *c, DBatch *b) {
     memset(b, 0, sizeof(*b));
     b->n_contig = c->n;
     b->meta = (DMeta *)c->b_meta.p;
+    b->tot = (DTotals *)c->b_tot.p;
+    current_caps(c, &b->caps);
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
     b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
@@ -245,12 +274,14 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->n = n;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
+    c->max_len = 0;
     int64_t off = 0, words = 0, items = 0, nbw = 0;
     for (int i = 0; i < n; i++) {
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
         DMeta &m = c->meta[(size_t)i];
         memset(&m, 0, sizeof(m));
+        c->max_len = std::max<int64_t>(c->max_len, L);
         m.off = offsets_or_null ? offsets_or_null[i] : off;
         m.L = (int32_t)L;
         int nt = 0;
@@ -393,8 +424,9 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
-                     &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot};
+                     &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
+    if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_t6) (void)hipFree(c->d_t6);
     if (c->d_t5) (void)hipFree(c->d_t5);
@@ -442,18 +474,21 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
 
 static double host_contig_pstop(uint32_t gc, int L);
 
-int phx_run(phx_ctx *c) {
-    if (!c) return PHX_E_ARG;
-    if (!c->uploaded) return PHX_E_STATE;
-    HIPCHK(c, hipSetDevice(c->device));
+namespace {
+
+const int kRetry = 1000; // run_once: a buffer was too small for this batch (or a solver class was not launched): run again, sizing as we go
+
+// One pass over the whole path.  `learn`: read the device-side totals back after each layout kernel and size the buffers
+// from them (two extra host round trips: first run of a context, or a batch that outgrew it).  Otherwise everything is
+// enqueued at once against the buffers the context already has; the layout kernels flag a batch that does not fit, later
+// kernels then do nothing, and the caller runs again with `learn`.
+int run_once(phx_ctx *c, bool learn) {
     int rc;
     const int n = c->n;
-    c->ran = false;
-    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
-    if (n == 0) { c->ran = true; return PHX_OK; }
-    if ((rc = ensure_position_buffers(c))) return rc;
     hipStream_t s = c->stream;
-    (void)0;
+    if ((rc = ensure_position_buffers(c))) return rc;
+    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
+    if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
     // reset per-contig accumulators (offsets and lengths stay)
     for (DMeta &m : c->meta) {
         DMeta k = m;
@@ -465,6 +500,7 @@ int phx_run(phx_ctx *c) {
         StageTimer t(c, ST_MEMSET);
         HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
         HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
+        HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
     }
     {
         StageTimer t(c, ST_COPY);
@@ -473,139 +509,110 @@ int phx_run(phx_ctx *c) {
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
-    { StageTimer t(c, ST_ORF_COUNT); phxk_orf_count(&b, s); }
+    { StageTimer t(c, ST_ORF_COUNT); phxk_orf_count(&b, s); phxk_layout1(&b, s); }
     HIPCHK(c, hipGetLastError());
-    { // sync #1: ORF / group counts -> offsets
-        StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(c, hipStreamSynchronize(s));
-    int64_t o = 0, g = 0, v = 0, cb = 0;
-    for (DMeta &m : c->meta) {
-        m.orf_off = o; m.grp_off = g; m.node_off = v;
-        m.n_node = m.status < 0 ? 0 : m.n_orf + m.n_grp + 2;
-        m.cb_off = cb; m.ncw = m.n_node / 64 + 1;
-        o += m.n_orf; g += m.n_grp; v += m.n_node; cb += 2 * (int64_t)m.ncw;
-    }
-    if ((rc = ensure(c, c->b_cbits, (size_t)(cb + 8) * 8))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->b_cbits.p, 0, (size_t)(cb + 8) * 8, s));
-    c->tot_orf = o; c->tot_grp = g; c->tot_node = v;
-    if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(o + 1)))) return rc;
-    if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * (size_t)(g + 1)))) return rc;
-    const size_t NV = (size_t)v + 8;
-    if ((rc = ensure(c, c->b_npos, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_ninfo, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_nother, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_parent, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_nlink, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
-    if ((rc = ensure(c, c->b_path, NV * 4))) return rc;
-    if ((rc = ensure(c, c->b_genes, sizeof(DGene) * (size_t)(g + 1)))) return rc;
-    {
-        StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+    DTotals *ht = c->h_tot;
+    if (learn) { // sync #1: totals of ORFs / groups / nodes -> buffers
+        { StageTimer t(c, ST_COPY); HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s)); }
+        HIPCHK(c, hipStreamSynchronize(s));
+        const size_t NV = (size_t)ht->node + 8, G = (size_t)ht->grp + 1;
+        if ((rc = ensure(c, c->b_cbits, (size_t)(ht->cb + 8) * 8))) return rc;
+        if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
+        if ((rc = ensure(c, c->b_genes, sizeof(DGene) * G))) return rc;
+        for (DevBuf *q : {&c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_path})
+            if ((rc = ensure(c, *q, NV * 4))) return rc;
+        if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
+        if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
+        if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)std::max(c->n_limbs, 2)))) return rc;
+        HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s)); // the offsets stand; the capacities are now sufficient
     }
     fill_batch(c, &b);
+    HIPCHK(c, hipMemsetAsync(c->b_cbits.p, 0, (size_t)(b.caps.cb + 8) * 8, s));
     { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
     { StageTimer t(c, ST_ORF_STATS); phxk_orf_stats(&b, s); }
     { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
     { StageTimer t(c, ST_NODES); phxk_nodes(&b, s); }
-    { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); }
+    { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); phxk_layout2(&b, s); }
     HIPCHK(c, hipGetLastError());
-    { // sync #2: edge counts, weight magnitudes
-        StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(c, hipStreamSynchronize(s));
-    int64_t e = 0;
-    int nlmax = 2;
-    struct Cls { bool any = false; size_t lds = 0; } cls[4][3]; // [limb class][mode]
-    const int nl_of[4] = {2, 4, 8, 17};
-    const bool no_wave = getenv("PHX_SSSP_NOWAVE") != nullptr; // test hook: keep every contig off the wavefront kernel
-    for (DMeta &m : c->meta) {
-        m.edge_off = e;
-        m.sssp_nl = 2; m.sssp_mode = 0; m.sssp_fb = 0;
-        if (m.status < 0) { m.n_edge = 0; continue; }
-        e += m.n_edge;
-        // A tentative distance is the length of a walk that uses every ORF edge at most once (a shortest path is simple;
-        // longer walks never win), so |dist| <= B = sum |w_orf| + (V/2) * max |w_connector|.  The connector bound follows
-        // functions.py:26-46: overlap < 500 bp, gap <= 300 bp or bridge pow(.)+length; terminals are smaller still.
-        // A candidate d(u)+w needs one more bit, the sign another, and the "unreached" pattern sits two bits higher;
-        // one bit covers the rounding of the fp64 sum.
-        int bits = 4096;
-        if (m.maxexp < 2000) {
-            const double pst = host_contig_pstop(m.gc, (int)m.L);
-            const double cmax = std::max(std::max(1.0 / std::pow(1.0 - pst, 500.0), 1.0 / std::pow(1.0 - pst, 100.0)) + 20.0, (double)m.L + 21.0) * 1000.0;
-            const double bound = m.wsum + 0.5 * (double)std::max(m.n_node, 2) * cmax;
-            int eb = 0;
-            (void)std::frexp(bound, &eb);
-            bits = std::max(eb, m.maxexp) + 5;
-        }
-        int k = bits <= 128 ? 0 : bits <= 256 ? 1 : bits <= 512 ? 2 : 3;
-        if (getenv("PHX_DEBUG_BITS")) fprintf(stderr, "bits %d maxexp %d V %d\n", bits, m.maxexp, m.n_node);
-        if (bits > 17 * 64) { m.status = PHX_S_OVERFLOW; continue; }
-        m.sssp_nl = nl_of[k];
-        nlmax = std::max(nlmax, m.sssp_nl);
-        const size_t lds = phxk_sssp_lds_bytes(m.n_node, m.sssp_nl);
-        // the kernel a contig falls back to when the wavefront kernel hands it back (and the one it gets otherwise)
-        m.sssp_fb = c->force_global_sssp ? 0 : lds <= 158 * 1024 ? 1 : 0;
-        m.sssp_mode = (!c->force_global_sssp && !no_wave && phxk_sssp_wave_ok(m.sssp_nl)) ? 2 : m.sssp_fb;
-        if (m.n_node > 2) {
-            cls[k][m.sssp_mode].any = true;
-            if (m.sssp_mode == 2) cls[k][m.sssp_fb].any = true; // launched after the wavefront kernel, on the same stream
-            if (m.sssp_fb == 1) cls[k][1].lds = std::max(cls[k][1].lds, lds);
-        }
-    }
-    c->tot_edge = e;
-    c->n_limbs = nlmax;
-    if ((rc = ensure(c, c->b_esrc, (size_t)(e + 1) * 4))) return rc;
-    if ((rc = ensure(c, c->b_ew, (size_t)(e + 1) * 8))) return rc;
-    if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)nlmax))) return rc;
-    {
-        StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+    int mask = c->last_mask;
+    int64_t lds[4] = {c->last_lds[0], c->last_lds[1], c->last_lds[2], c->last_lds[3]};
+    int64_t n_edges = b.caps.edge;
+    if (learn) { // sync #2: edge total, widest integer class, solver classes
+        { StageTimer t(c, ST_COPY); HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s)); }
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->n_limbs = std::max(c->n_limbs, std::max(ht->nlmax, 2));
+        if ((rc = ensure(c, c->b_esrc, (size_t)(ht->edge + 1) * 4))) return rc;
+        if ((rc = ensure(c, c->b_ew, (size_t)(ht->edge + 1) * 8))) return rc;
+        if ((rc = ensure(c, c->b_dist, ((size_t)ht->node + 8) * 8 * (size_t)c->n_limbs))) return rc;
+        HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s));
+        mask = ht->class_mask;
+        for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
+        n_edges = ht->edge;
     }
     fill_batch(c, &b);
     {
-        int maxv = 0;
-        for (const DMeta &m : c->meta) maxv = std::max(maxv, m.n_node);
-        b.defer_overlap = maxv < (1 << 21) ? 1 : 0;
+        b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
         StageTimer t(c, ST_EDGE_FILL);
-        phxk_edges_fill(&b, e, s);
+        phxk_edges_fill(&b, n_edges, s);
     }
     {
-        // one launch per (limb class, memory mode) that occurs in the batch; the launches are independent
-        // (disjoint contigs), so all but the first go to side streams and overlap
+        // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
+        // wavefront kernel first, then the kernels it may hand contigs to
         StageTimer t(c, ST_SSSP);
-        int nlaunch = 0;
+        const int nl_of[4] = {2, 4, 8, 17};
+        int nlaunch = 0, nclass = 0;
         bool used[3] = {false, false, false};
-        int nclass = 0;
-        for (int k = 0; k < 4; k++) nclass += (cls[k][0].any || cls[k][1].any || cls[k][2].any) ? 1 : 0;
+        for (int k = 0; k < 4; k++) nclass += ((mask >> (4 * k)) & 7) ? 1 : 0;
         if (nclass > 1 && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
         for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
-            if (!cls[k][0].any && !cls[k][1].any && !cls[k][2].any) continue;
+            if (!((mask >> (4 * k)) & 7)) continue;
             hipStream_t st = s;
             if (nlaunch > 0 && c->aux[0]) {
                 const int a = (nlaunch - 1) % 3;
                 if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
                 st = c->aux[a];
             }
-            // one stream per limb class; within it the wavefront kernel first, then the kernels it may hand contigs to
             for (int mode = 2; mode >= 0; mode--)
-                if (cls[k][mode].any) phxk_sssp(&b, nl_of[k], mode, cls[k][mode].lds, st);
+                if ((mask >> (4 * k + mode)) & 1) phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
             nlaunch++;
         }
         for (int a = 0; a < 3; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
     }
     HIPCHK(c, hipGetLastError());
-    { // sync #3: statuses, gene counts
+    { // final sync: per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
         HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
+    if (ht->overflow) return kRetry;
+    bool covered = (ht->class_mask & ~mask) == 0;
+    for (int k = 0; k < 4; k++) covered = covered && ht->lds_need[k] <= lds[k];
+    if (!covered) { c->last_mask = ht->class_mask; for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k]; return kRetry; }
+    c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
+    c->last_mask = ht->class_mask;
+    for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k];
+    c->have_plan = true;
+    return PHX_OK;
+}
+
+} // namespace
+
+int phx_run(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (!c->uploaded) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ran = false;
+    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
+    if (c->n == 0) { c->ran = true; return PHX_OK; }
+    int rc = run_once(c, !c->have_plan || getenv("PHX_ALWAYS_SYNC") != nullptr);
+    for (int attempt = 0; rc == kRetry && attempt < 3; attempt++) rc = run_once(c, true);
+    if (rc == kRetry) { c->err = "batch layout did not settle"; return PHX_E_STATE; }
+    if (rc) return rc;
+    const int n = c->n;
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_WAVE")) {
         int nfb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nw = 0;
@@ -906,8 +913,10 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     if ((rc = ensure(c, c->b_ewl, ((size_t)E + 1) * 8 * (size_t)n_limbs))) return rc;
     if ((rc = ensure(c, c->b_dist, ((size_t)V + 1) * 8 * (size_t)n_limbs))) return rc;
     if ((rc = ensure(c, c->b_parent, ((size_t)V + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
     c->uploaded = false; c->ran = false; // the batch buffers are being reused
     hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
     HIPCHK(c, hipMemcpyAsync(b_meta.p, &m, sizeof(m), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->b_inoff.p, in_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, s));
     if (E) {
@@ -918,6 +927,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     memset(&b, 0, sizeof(b));
     b.n_contig = 1;
     b.meta = (DMeta *)b_meta.p;
+    b.tot = (DTotals *)c->b_tot.p;
     b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (double *)c->b_ew.p;
     b.ewl = (const uint64_t *)c->b_ewl.p;
     b.dist = (uint64_t *)c->b_dist.p; b.parent = (int32_t *)c->b_parent.p;

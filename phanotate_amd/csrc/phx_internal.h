@@ -124,9 +124,27 @@ struct DGene {
 };
 
 // Everything the kernels need, passed by value.
+// Batch totals and decisions computed on the device (k_layout1 / k_layout2), so that a run needs no host round trip
+// when the buffers of the context are already large enough; the host reads them back with the final results.
+struct DTotals {
+    int64_t orf, grp, node, cb, edge; // totals over the batch
+    int32_t nlmax;       // widest integer class (64-bit limbs) any contig needs
+    int32_t class_mask;  // bit 4*k + mode: some contig wants limb class k (2,4,8,17 limbs) solved by kernel `mode`
+    int32_t vmax;        // largest node count
+    int32_t overflow;    // bit 0: ORF/node buffers, bit 1: edge/distance buffers too small -> the later kernels do nothing
+    int64_t lds_need[4]; // per limb class: dynamic LDS k_sssp_lds needs (max over the contigs it may get)
+};
+struct DCaps {
+    int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
+    int32_t limbs;                    // 64-bit words per node in `dist`
+    int32_t flags;                    // bit 0: force the global-memory solver, bit 1: keep contigs off the wavefront kernel
+};
+
 struct DBatch {
     int32_t n_contig;
     DMeta *meta;
+    DTotals *tot;
+    DCaps caps;
     const DParams *params;
     const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;
     // per position
@@ -170,6 +188,8 @@ void phxk_train(const DBatch *b, void *stream);
 void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
+void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
+void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for

@@ -568,6 +568,7 @@ __device__ __forceinline__ FrameBits frame_bits(const uint64_t *bits, int nw, in
 
 template <bool EMIT>
 __global__ __launch_bounds__(NT) void k_orf(DBatch b) {
+    if (EMIT && b.tot->overflow) return;
     __shared__ uint32_t s_scan[NT / 64 + 1];
     DMeta *meta = &b.meta[blockIdx.x];
     const int L = meta->L;
@@ -684,6 +685,7 @@ __device__ __forceinline__ void class_hist(const uint64_t *__restrict__ M, size_
 }
 
 __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
     DOrf *orf = b.orf + meta->orf_off;
@@ -757,6 +759,7 @@ __global__ __launch_bounds__(NT) void k_orf_stats(DBatch b) {
 // ORF weight: functions.py:254-257 (RBS), 281-284 (normalise), 286-301 + orfs.py:122-127.
 // hold = prod ((1-pstop)^pos_max[imax])^pos_min[imin] = (1-pstop)^S ; weight = -(1/hold)*w_start*w_rbs
 __global__ __launch_bounds__(NT) void k_score(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     __shared__ int s_maxexp;
     __shared__ double s_wsum;
     DMeta *meta = &b.meta[blockIdx.x];
@@ -823,6 +826,7 @@ __device__ __forceinline__ LinkInfo link_info(uint32_t link, const DOrf *orf, co
 
 // coverage by the longest ORF of every stop-group (functions.py:321-330), 16 lanes per group, one atomicOr per word
 __global__ __launch_bounds__(NT) void k_node_cov(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0) return;
     const int L = meta->L;
@@ -843,6 +847,7 @@ __global__ __launch_bounds__(NT) void k_node_cov(DBatch b) {
 
 // per-word node-rank bases, and the bridge events (a covered base more than 500 after the previous covered base)
 __global__ __launch_bounds__(NT) void k_node_rank(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     __shared__ uint32_t s_scan[NT / 64 + 1];
     DMeta *meta = &b.meta[blockIdx.x];
     const int tid = threadIdx.x;
@@ -904,6 +909,7 @@ __device__ __forceinline__ int node_rank(const uint64_t *nbF, const uint64_t *nb
 
 // every ORF writes its start node, every stop-group its stop node (functions.py:311-318)
 __global__ __launch_bounds__(NT) void k_node_build(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0 || meta->n_node <= 2) return;
     const int nwp = 3 * meta->nw;
@@ -933,6 +939,7 @@ __global__ __launch_bounds__(NT) void k_node_build(DBatch b) {
 
 // other_end[pos] (last writer wins, orfs.py:19-30) and the o1/o2 term (functions.py:373-384), thread per node
 __global__ __launch_bounds__(NT) void k_node_attr(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0 || meta->n_node <= 2) return;
     const int L = meta->L;
@@ -1025,6 +1032,7 @@ __device__ __forceinline__ void emit_overlap(EdgeSink &s, int src, int length, b
 //   * right neighbours (overlap edges, functions.py:406-416,423-426,434-438): the other_end tests decide per candidate.
 template <bool FILL>
 __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0 || meta->n_node <= 0) return;
     const int L = meta->L;
@@ -1176,9 +1184,9 @@ __global__ __launch_bounds__(NT) void k_edges(DBatch b) {
 }
 
 // dense pass over the batch's edge arrays: finish the overlap weights recorded by k_edges<true>
-__global__ __launch_bounds__(256) void k_edge_weights(uint32_t *__restrict__ esrc, double *__restrict__ ew, int64_t n) {
+__global__ __launch_bounds__(256) void k_edge_weights(uint32_t *__restrict__ esrc, double *__restrict__ ew, const DTotals *__restrict__ tot) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    if (tot->overflow || e >= tot->edge) return;
     const uint32_t sv = esrc[e];
     if (sv & EDGE_PENDING) {
         const int length = (int)((sv >> 21) & 511u);
@@ -1189,6 +1197,7 @@ __global__ __launch_bounds__(256) void k_edge_weights(uint32_t *__restrict__ esr
 
 // in-degrees -> exclusive offsets (CSR by destination), one workgroup per contig
 __global__ __launch_bounds__(NT) void k_edges_scan(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     __shared__ uint32_t s_scan[NT / 64 + 1];
     DMeta *meta = &b.meta[blockIdx.x];
     if (meta->status < 0 || meta->n_node <= 0) {
@@ -1353,6 +1362,7 @@ __device__ void emit_path_and_genes(const DBatch &b, DMeta *meta, const uint32_t
 // ---- general kernel: distances in global memory (any V); also serves phx_solve ----
 template <int NL>
 __global__ __launch_bounds__(NT) void k_sssp(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     __shared__ int s_flag[2];
     DMeta *meta = &b.meta[blockIdx.x];
     const int V = meta->n_node;
@@ -1430,6 +1440,7 @@ __global__ __launch_bounds__(NT) void k_sssp(DBatch b) {
 
 template <int NL>
 __global__ void k_path(DBatch b) {
+    if (b.tot->overflow) return; // a buffer of this run is too small: the host grows it and runs again
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= b.n_contig) return;
     DMeta *meta = &b.meta[c];
@@ -1530,8 +1541,13 @@ __device__ __forceinline__ uint32_t u32_row_min(uint32_t x, int sub) {
 #ifndef SW_WPS
 #define SW_WPS 6 // wavefronts per SIMD the register allocation must allow (workgroups/CU = SW_WPS * 256 / SW_THREADS)
 #endif
+// fixed-size ring of distances + in-edge tile + one plan byte per window of SW_ADV nodes
+__host__ __device__ inline size_t sssp_lds_bytes(int V, int nl) {
+    return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + (size_t)(V / SW_ADV + 1) + 64;
+}
 template <int NL>
-__global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int mode) {
+__global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int mode, int lds_given) {
+    if (b.tot->overflow) return;
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_flag[2];
     __shared__ int s_np, s_nclose, s_viol;
@@ -1540,6 +1556,7 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
     DMeta *meta = &b.meta[blockIdx.x];
     const int V = meta->n_node;
     if (meta->status < 0 || V <= 2 || meta->sssp_nl != NL || meta->sssp_mode != mode) return;
+    if (sssp_lds_bytes(V, NL) > (size_t)lds_given) return; // launched with less LDS than this contig needs: left unsolved (sweeps == 0), the host launches again
     const int tid = threadIdx.x;
     const int SRC = V - 2, TGT = V - 1, ncds = V - 2;
     const uint32_t *in_off = b.in_off + meta->node_off + blockIdx.x;
@@ -1868,6 +1885,125 @@ __global__ __launch_bounds__(SW_THREADS, SW_WPS) void k_sssp_lds(DBatch b, int m
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Batch layout on the device.  One workgroup walks the contigs (a scan per 1024), so that no host round trip is
+// needed between the counting and the emitting kernels when the buffers of the context are large enough.
+#define LAYOUT_T 1024
+// four running sums at once
+__device__ __forceinline__ void layout_scan4(int64_t v[4], int64_t base[4], int64_t *s_part /* [4][LAYOUT_T/64 + 1] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t inc[4];
+    for (int q = 0; q < 4; q++) {
+        int64_t x = v[q];
+        for (int d = 1; d < 64; d <<= 1) { const int64_t t = __shfl_up(x, d); if (lane >= d) x += t; }
+        inc[q] = x;
+        if (lane == 63) s_part[q * 17 + w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) { int64_t a = 0; for (int i = 0; i < LAYOUT_T / 64; i++) { const int64_t t = s_part[threadIdx.x * 17 + i]; s_part[threadIdx.x * 17 + i] = a; a += t; } s_part[threadIdx.x * 17 + 16] = a; }
+    __syncthreads();
+    for (int q = 0; q < 4; q++) { const int64_t ex = base[q] + s_part[q * 17 + w] + inc[q] - v[q]; const int64_t tot = s_part[q * 17 + 16]; v[q] = ex; inc[q] = tot; }
+    __syncthreads();
+    for (int q = 0; q < 4; q++) base[q] += inc[q];
+}
+// after k_orf<false>: ORF / group / node / close-bitmap offsets (what phx_run did on the host between two syncs)
+__global__ __launch_bounds__(LAYOUT_T) void k_layout1(DBatch b) {
+    __shared__ int64_t s_part[4 * 17];
+    int64_t base[4] = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < b.n_contig; i0 += LAYOUT_T) {
+        const int i = i0 + (int)threadIdx.x;
+        int64_t v[4] = {0, 0, 0, 0};
+        int n_node = 0, ncw = 0;
+        if (i < b.n_contig) {
+            DMeta *m = &b.meta[i];
+            n_node = m->status < 0 ? 0 : m->n_orf + m->n_grp + 2;
+            ncw = n_node / 64 + 1;
+            v[0] = m->n_orf; v[1] = m->n_grp; v[2] = n_node; v[3] = 2 * (int64_t)ncw;
+        }
+        layout_scan4(v, base, s_part);
+        if (i < b.n_contig) {
+            DMeta *m = &b.meta[i];
+            m->orf_off = v[0]; m->grp_off = v[1]; m->node_off = v[2]; m->cb_off = v[3];
+            m->n_node = n_node; m->ncw = ncw;
+        }
+    }
+    if (threadIdx.x == 0) {
+        DTotals *t = b.tot;
+        t->orf = base[0]; t->grp = base[1]; t->node = base[2]; t->cb = base[3];
+        if (base[0] > b.caps.orf || base[1] > b.caps.grp || base[2] > b.caps.node || base[3] > b.caps.cb) t->overflow |= 1;
+    }
+}
+
+
+// after k_edges<false>: edge offsets; per contig the integer width its path sums need and the kernel that solves it
+__global__ __launch_bounds__(LAYOUT_T) void k_layout2(DBatch b) {
+    __shared__ int64_t s_part[4 * 17];
+    __shared__ int s_nl, s_mask, s_vmax;
+    __shared__ unsigned long long s_lds[4];
+    if (b.tot->overflow) return;
+    if (threadIdx.x == 0) { s_nl = 2; s_mask = 0; s_vmax = 0; for (int k = 0; k < 4; k++) s_lds[k] = 0; }
+    __syncthreads();
+    int64_t base[4] = {0, 0, 0, 0};
+    const bool force_global = b.caps.flags & 1, no_wave = (b.caps.flags & 2) != 0;
+    for (int i0 = 0; i0 < b.n_contig; i0 += LAYOUT_T) {
+        const int i = i0 + (int)threadIdx.x;
+        int64_t v[4] = {0, 0, 0, 0};
+        if (i < b.n_contig) {
+            DMeta *m = &b.meta[i];
+            m->sssp_nl = 2; m->sssp_mode = 0; m->sssp_fb = 0;
+            if (m->status < 0) m->n_edge = 0;
+            else {
+                v[0] = m->n_edge;
+                // A tentative distance is the length of a walk that uses every ORF edge at most once (a shortest path is
+                // simple; longer walks never win), so |dist| <= B = sum |w_orf| + (V/2) * max |w_connector|.  The connector
+                // bound follows functions.py:26-46: overlap < 500 bp, gap <= 300 bp or bridge pow(.)+length; terminals are
+                // smaller still.  A candidate d(u)+w needs one more bit, the sign another, the "unreached" pattern sits two
+                // bits higher; one bit covers the rounding of the fp64 sum.
+                int bits = 4096;
+                if (m->maxexp < 2000) {
+                    const double pst = contig_pstop(m->gc, m->L);
+                    double cmax = 1.0 / pow(1.0 - pst, 500.0);
+                    const double c2 = 1.0 / pow(1.0 - pst, 100.0);
+                    cmax = (cmax > c2 ? cmax : c2) + 20.0;
+                    const double c3 = (double)m->L + 21.0;
+                    cmax = (cmax > c3 ? cmax : c3) * 1000.0;
+                    const double bound = m->wsum + 0.5 * (double)(m->n_node > 2 ? m->n_node : 2) * cmax;
+                    int eb = 0;
+                    (void)frexp(bound, &eb);
+                    bits = (eb > m->maxexp ? eb : m->maxexp) + 5;
+                }
+                if (bits > 17 * 64) m->status = PHX_S_OVERFLOW;
+                else {
+                    const int k = bits <= 128 ? 0 : bits <= 256 ? 1 : bits <= 512 ? 2 : 3;
+                    const int nl = k == 0 ? 2 : k == 1 ? 4 : k == 2 ? 8 : 17;
+                    m->sssp_nl = nl;
+                    const size_t lds = sssp_lds_bytes(m->n_node, nl);
+                    // the kernel a contig falls back to when the wavefront kernel hands it back (and the one it gets otherwise)
+                    const int fb = force_global ? 0 : (lds <= 158 * 1024 ? 1 : 0);
+                    const int mode = (!force_global && !no_wave && nl == 2) ? 2 : fb;
+                    m->sssp_fb = fb; m->sssp_mode = mode;
+                    atomicMax(&s_nl, nl);
+                    if (m->n_node > 2) {
+                        atomicOr(&s_mask, (1 << (4 * k + mode)) | (mode == 2 ? 1 << (4 * k + fb) : 0));
+                        if (fb == 1) atomicMax(&s_lds[k], (unsigned long long)lds);
+                        atomicMax(&s_vmax, m->n_node);
+                    }
+                }
+            }
+        }
+        layout_scan4(v, base, s_part);
+        if (i < b.n_contig) b.meta[i].edge_off = v[0];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DTotals *t = b.tot;
+        t->edge = base[0]; t->nlmax = s_nl; t->class_mask = s_mask; t->vmax = s_vmax;
+        for (int k = 0; k < 4; k++) t->lds_need[k] = (int64_t)s_lds[k];
+        if (base[0] + 1 > b.caps.edge || s_nl > b.caps.limbs) t->overflow |= 2;
+    }
+}
+
 #include "phx_sssp_wave.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1894,7 +2030,7 @@ void phxk_edges_count(const DBatch *b, void *stream) {
 void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream) {
     hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     if (b->defer_overlap && n_edges > 0)
-        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->esrc, b->ew, n_edges);
+        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
 }
 // phx_solve: the relaxation alone, no path/gene emission (the caller walks the parent edges)
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
@@ -1908,10 +2044,9 @@ void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
     }
 }
 
-size_t phxk_sssp_lds_bytes(int V, int nl) {
-    // fixed-size ring of distances + in-edge tile + one plan byte per window of SW_ADV nodes
-    return (size_t)(SW_RING + 1) * nl * 8 + (size_t)SW_ECAP * ((size_t)nl * 8 + 4) + (size_t)(V / SW_ADV + 1) + 64;
-}
+size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
+void phxk_layout1(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout1, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); }
+void phxk_layout2(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout2, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); }
 
 int phxk_sssp_wave_ok(int nl) { return nl == 2; }
 
@@ -1939,16 +2074,16 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
     switch (nl) {
     case 2:
         (void)hipFuncSetAttribute((const void *)k_sssp_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k_sssp_lds<2>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+        hipLaunchKernelGGL(k_sssp_lds<2>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode, (int)lds_bytes); break;
     case 4:
         (void)hipFuncSetAttribute((const void *)k_sssp_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k_sssp_lds<4>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+        hipLaunchKernelGGL(k_sssp_lds<4>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode, (int)lds_bytes); break;
     case 8:
         (void)hipFuncSetAttribute((const void *)k_sssp_lds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k_sssp_lds<8>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+        hipLaunchKernelGGL(k_sssp_lds<8>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode, (int)lds_bytes); break;
     default:
         (void)hipFuncSetAttribute((const void *)k_sssp_lds<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(k_sssp_lds<17>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode); break;
+        hipLaunchKernelGGL(k_sssp_lds<17>, g, dim3(SW_THREADS), lds_bytes, s, *b, mode, (int)lds_bytes); break;
     }
 }
 }

@@ -522,3 +522,32 @@ def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, exp
     p, d = ann.path(0)
     assert abs(d - dist) <= abs(dist) * 1e-12
     ann.close()
+
+
+def test_context_reuse_across_growing_and_changing_batches(pa, oracle):
+    """One context, batches of different shapes back to back.  A run enqueues everything against the buffers and the
+    solver classes of the previous run and validates on the device: a batch that outgrows the buffers, or that needs an
+    integer class / kernel the previous one did not, must transparently run again and still equal the oracle."""
+    rng = np.random.RandomState(11)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    long_orf = pa.synth_contig(900, 3000).decode() + "atg" + "".join(rng.choice(sense, 5500)) + "taa" + pa.synth_contig(901, 3000).decode()
+    batches = [
+        [pa.synth_contig(500 + i, 3000).decode() for i in range(3)],
+        [pa.synth_contig(600 + i, 20000).decode() for i in range(6)],           # outgrows every buffer
+        [pa.synth_contig(700, 5000).decode(), long_orf],                        # a wide-integer contig: another solver class
+        [pa.synth_contig(800 + i, 2000).decode() for i in range(2)] + ["acgtn", ""],  # smaller again, with degenerate contigs
+        [pa.synth_contig(600 + i, 20000).decode() for i in range(6)],           # fits now: no host round trip
+    ]
+    ann = pa.Annotator()
+    saw_wide = False
+    for seqs in batches:
+        res = ann.annotate(seqs)
+        for i, (s, (status, genes)) in enumerate(zip(seqs, res)):
+            if s is long_orf:
+                saw_wide = ann.globals(i).n_limbs > 2
+                dist, want = _py_bellman_ford_genes(oracle.run(s, stages=2))
+                assert [(int(g["left"]), int(g["right"])) for g in genes] == want
+            else:
+                check_contig(ann, i, s, oracle.run(s), genes, status)
+    assert saw_wide
+    ann.close()
