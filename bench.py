@@ -90,10 +90,14 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ann = pa.Annotator(device=local_rank, stream=stream)
 
-    # PCIe-inclusive pass (H2D + kernels + D2H), reported on stderr only — never `value`
-    t0 = time.perf_counter()
+    # PCIe-inclusive pass (H2D of the ASCII + kernels + D2H of the gene lists): the second call, when the context's
+    # buffers exist.  Reported as `pcie_inclusive_Mbp_s` — never `value`.
     res = ann.annotate(seqs)
-    t_e2e = time.perf_counter() - t0
+    t_e2e = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = ann.annotate(seqs)
+        t_e2e = min(t_e2e, time.perf_counter() - t0)
     n_genes = sum(len(g) for _, g in res)
     n_bad = sum(1 for st, _ in res if st < 0)
 
