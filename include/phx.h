@@ -149,6 +149,10 @@ int phx_upload(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *l
 int phx_attach(phx_ctx *ctx, int32_t n, const void *d_ascii, const int64_t *offsets);
 int phx_run(phx_ctx *ctx);                        /* every kernel of the path; blocks until results are in HBM */
 int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] */
+/* The same into caller-owned flat arrays (what a language binding wants: no per-contig allocation): genes of contig i are
+ * genes[offsets[i] .. offsets[i+1]), in path order; status[i] as phx_result.status.  offsets has n+1 entries.  With
+ * genes == NULL only offsets, status and total are filled (size query); cap = number of phx_gene records genes can take. */
+int phx_download_flat(phx_ctx *ctx, phx_gene *genes, int64_t cap, int64_t *offsets /* [n+1] */, int32_t *status /* [n] */, int64_t *total);
 
 /* ---- stage taps on the batch last processed by phx_run (parity tests) ---- */
 int phx_tap_globals(phx_ctx *ctx, int32_t contig, phx_globals *out);

@@ -94,19 +94,18 @@ class Annotator:
         self._chk(self.L.phx_run(self.h), "phx_run")
 
     def download(self):
-        res = (_lib.Result * max(self.n, 1))()
-        self._chk(self.L.phx_download(self.h, res), "phx_download")
-        out = []
-        for i in range(self.n):
-            r = res[i]
-            if r.n_genes:
-                raw = np.ctypeslib.as_array(C.cast(r.genes, C.POINTER(C.c_uint8)), (r.n_genes * _lib.GENE_DT.itemsize,))
-                genes = raw.view(_lib.GENE_DT).copy()
-            else:
-                genes = np.zeros(0, _lib.GENE_DT)
-            out.append((int(r.status), genes))
-        self.L.phx_free_results(res, self.n)
-        return out
+        """[(status, genes structured array)] per contig; the arrays are views into one flat buffer (phx_download_flat)."""
+        n = self.n
+        offs = np.zeros(n + 1, np.int64)
+        status = np.zeros(max(n, 1), np.int32)
+        total = C.c_int64(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.phx_download_flat(self.h, None, 0, vp(offs), vp(status), C.byref(total)), "phx_download_flat")
+        genes = np.zeros(max(int(total.value), 1), _lib.GENE_DT)
+        self._chk(self.L.phx_download_flat(self.h, vp(genes), len(genes), vp(offs), vp(status), C.byref(total)), "phx_download_flat")
+        o = offs.tolist()
+        st = status.tolist()
+        return [(st[i], genes[o[i]:o[i + 1]]) for i in range(n)]
 
     def annotate(self, seqs):
         """[(status, genes structured array)] for every contig, in input order."""

@@ -456,9 +456,18 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         HIPCHK(c, hipHostMalloc(&c->h_stage, T + T / 8, hipHostMallocDefault));
         c->h_stage_cap = T + T / 8;
     }
-    for (int i = 0; i < n; i++) memcpy((char *)c->h_stage + c->meta[(size_t)i].off, seq[i], (size_t)len[i]);
+    // stage into pinned memory and send in pieces, so that the DMA of one piece overlaps the staging of the next
     StageTimer t(c, ST_COPY);
-    HIPCHK(c, hipMemcpyAsync(c->b_ascii.p, c->h_stage, (size_t)c->totalL, hipMemcpyHostToDevice, c->stream));
+    const int64_t piece = 4 << 20;
+    int64_t sent = 0;
+    for (int i = 0; i < n; i++) {
+        memcpy((char *)c->h_stage + c->meta[(size_t)i].off, seq[i], (size_t)len[i]);
+        const int64_t end = i + 1 < n ? c->meta[(size_t)i + 1].off : c->totalL; // rows are 16-byte aligned: the gap belongs to the piece
+        if (end - sent >= piece || i + 1 == n) {
+            HIPCHK(c, hipMemcpyAsync((char *)c->b_ascii.p + sent, (char *)c->h_stage + sent, (size_t)(end - sent), hipMemcpyHostToDevice, c->stream));
+            sent = end;
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHX_OK;
 }
@@ -668,6 +677,38 @@ int phx_download(phx_ctx *c, phx_result *out) {
             }
         }
     }
+    return PHX_OK;
+}
+
+int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets, int32_t *status, int64_t *total_out) {
+    if (!c || (c->n > 0 && (!offsets || !status))) return PHX_E_ARG;
+    if (!c->ran) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t total = 0, hi = 0;
+    for (const DMeta &m : c->meta) { total += m.status < 0 ? 0 : m.n_genes; hi = std::max<int64_t>(hi, m.gene_off + m.n_genes); }
+    if (total_out) *total_out = total;
+    if (!genes) { // size query
+        int64_t o = 0;
+        for (int i = 0; i < c->n; i++) { const DMeta &m = c->meta[(size_t)i]; offsets[i] = o; status[i] = m.status; o += m.status < 0 ? 0 : m.n_genes; }
+        if (c->n >= 0 && offsets) offsets[c->n] = o;
+        return PHX_OK;
+    }
+    if (cap < total) return PHX_E_ARG;
+    c->h_genes.resize((size_t)hi);
+    if (hi) {
+        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), c->b_genes.p, sizeof(DGene) * (size_t)hi, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    static_assert(sizeof(DGene) == sizeof(phx_gene), "device and ABI gene records have the same layout");
+    int64_t o = 0;
+    for (int i = 0; i < c->n; i++) {
+        const DMeta &m = c->meta[(size_t)i];
+        const int64_t k = m.status < 0 ? 0 : m.n_genes;
+        offsets[i] = o; status[i] = m.status;
+        if (k) memcpy(genes + o, &c->h_genes[(size_t)m.gene_off], sizeof(phx_gene) * (size_t)k);
+        o += k;
+    }
+    offsets[c->n] = o;
     return PHX_OK;
 }
 
