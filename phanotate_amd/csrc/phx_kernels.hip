@@ -142,7 +142,7 @@ void phxk_edges_count(const DBatch *b, void *stream) {
 void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream) {
     hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     if (b->defer_overlap && n_edges > 0)
-        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
+        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + EW_T * EW_PER - 1) / (EW_T * EW_PER))), dim3(EW_T), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
 }
 // phx_solve: the relaxation alone, no path/gene emission (the caller walks the parent edges)
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
