@@ -77,7 +77,7 @@ struct phx_ctx {
     DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
-    DevBuf b_npos, b_ninfo, b_nother, b_parent, b_nlink, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -232,8 +232,8 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
     k->orf = cap_of(c->b_orf, sizeof(DOrf), 1);
     k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, sizeof(DGene), 1));
-    int64_t v = cap_of(c->b_npos, 4, 8);
-    for (const DevBuf *q : {&c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_path}) v = std::min(v, cap_of(*q, 4, 8));
+    int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
+    for (const DevBuf *q : {&c->b_parent, &c->b_path}) v = std::min(v, cap_of(*q, 4, 8));
     v = std::min(v, cap_of(c->b_no, 8, 8));
     v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
     v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
@@ -258,8 +258,8 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
-    b->npos = (int32_t *)c->b_npos.p; b->ninfo = (int32_t *)c->b_ninfo.p; b->nother = (int32_t *)c->b_nother.p; b->parent = (int32_t *)c->b_parent.p;
-    b->nlink = (uint32_t *)c->b_nlink.p; b->in_off = (uint32_t *)c->b_inoff.p;
+    b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
+    b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
@@ -424,7 +424,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
-                     &c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -529,7 +529,8 @@ int run_once(phx_ctx *c, bool learn) {
         if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
         if ((rc = ensure(c, c->b_genes, sizeof(DGene) * G))) return rc;
-        for (DevBuf *q : {&c->b_npos, &c->b_ninfo, &c->b_nother, &c->b_parent, &c->b_nlink, &c->b_path})
+        if ((rc = ensure(c, c->b_node, NV * sizeof(DNode)))) return rc;
+        for (DevBuf *q : {&c->b_parent, &c->b_path})
             if ((rc = ensure(c, *q, NV * 4))) return rc;
         if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
         if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
@@ -843,32 +844,28 @@ int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
     if (m.status < 0 || m.n_node == 0) return PHX_OK;
     if (!out) return PHX_E_ARG;
     const size_t V = (size_t)m.n_node;
-    std::vector<int32_t> npos(V), ninfo(V), nother(V);
-    std::vector<uint32_t> nlink(V);
+    std::vector<DNode> nd(V);
     std::vector<double> no(V);
     std::vector<DGrp> grp((size_t)m.n_grp);
     std::vector<DOrf> orf((size_t)m.n_orf);
-    HIPCHK(c, hipMemcpy(npos.data(), (int32_t *)c->b_npos.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(ninfo.data(), (int32_t *)c->b_ninfo.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(nother.data(), (int32_t *)c->b_nother.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(nlink.data(), (uint32_t *)c->b_nlink.p + m.node_off, V * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nd.data(), (DNode *)c->b_node.p + m.node_off, V * sizeof(DNode), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(no.data(), (double *)c->b_no.p + m.node_off, V * 8, hipMemcpyDeviceToHost));
     if (m.n_grp) HIPCHK(c, hipMemcpy(grp.data(), (DGrp *)c->b_grp.p + m.grp_off, sizeof(DGrp) * grp.size(), hipMemcpyDeviceToHost));
     if (m.n_orf) HIPCHK(c, hipMemcpy(orf.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * orf.size(), hipMemcpyDeviceToHost));
     std::vector<int> order, ref_rank, ref_first;
     reference_order(grp, order, ref_rank, ref_first);
     for (size_t v = 0; v < V; v++) {
-        out[v].pos = npos[v]; out[v].type = (int8_t)NTYPE(ninfo[v]); out[v].frame = (int8_t)NFRAME(ninfo[v]); out[v].pad = 0;
-        out[v].other = nother[v]; out[v].o = no[v];
+        out[v].pos = nd[v].pos; out[v].type = (int8_t)NTYPE(nd[v].info); out[v].frame = (int8_t)NFRAME(nd[v].info); out[v].pad = 0;
+        out[v].other = nd[v].other; out[v].o = no[v];
         // reference insertion rank (functions.py:311-318): per ORF (source, target) in iter_orfs order
         int ref = -1;
         if (v + 2 == V) ref = m.n_orf + m.n_grp;
         else if (v + 1 == V) ref = m.n_orf + m.n_grp + 1;
-        else if (LINK_KIND(nlink[v]) == LINK_STOP) {
-            const size_t g = (size_t)LINK_IDX(nlink[v]);
+        else if (LINK_KIND(nd[v].link) == LINK_STOP) {
+            const size_t g = (size_t)LINK_IDX(nd[v].link);
             ref = ref_first[g] + ref_rank[g] + (grp[g].frame > 0 ? 1 : 0);
         } else {
-            const int k = (int)LINK_IDX(nlink[v]);
+            const int k = (int)LINK_IDX(nd[v].link);
             const size_t g = (size_t)orf[(size_t)k].grp;
             const int mth = k - grp[g].orf_begin;
             const int base = ref_first[g] + ref_rank[g];

@@ -6,7 +6,7 @@
 //   per ORF   (index = meta.orf_off + k, k in reference iter_orfs order):  DOrf (56 B)
 //   per group (index = meta.grp_off + g, g in reference insertion order):  DGrp (24 B)
 //   per node  (index = meta.node_off + v, v sorted by position; source = V-2, target = V-1):
-//       npos i32, ninfo i32, nlink u32, nother i32, no f64, in_off u32 (+1), dist NL x u64, parent i32
+//       DNode {pos i32, info i32, link u32, other i32}, no f64, in_off u32 (+1), dist NL x u64, parent i32
 //   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32, ew f64
 #pragma once
 #include <hip/hip_runtime.h>
@@ -123,6 +123,14 @@ struct DGene {
     double score;
 };
 
+// One node of the ORF graph (position-sorted; forward-strand slot before reverse-strand slot at equal positions).
+struct DNode {
+    int32_t pos;    // 1-based position (source 0, target L+1)
+    int32_t info;   // NINFO(type, frame)
+    uint32_t link;  // LINK_START | ORF index  or  LINK_STOP | group index
+    int32_t other;  // Orfs.other_end[pos] as get_graph sees it (k_node_attr)
+};
+
 // Everything the kernels need, passed by value.
 // Batch totals and decisions computed on the device (k_layout1 / k_layout2), so that a run needs no host round trip
 // when the buffers of the context are already large enough; the host reads them back with the final results.
@@ -160,8 +168,9 @@ struct DBatch {
     DOrf *orf;
     DGrp *grp;
     // per node
-    int32_t *npos, *ninfo, *nother, *parent;
-    uint32_t *nlink, *in_off;
+    DNode *node;        // position, type/frame, link to its ORF / group, other_end: one 16-byte record per node
+    int32_t *parent;
+    uint32_t *in_off;
     double *no;
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
