@@ -551,3 +551,19 @@ def test_context_reuse_across_growing_and_changing_batches(pa, oracle):
                 check_contig(ann, i, s, oracle.run(s), genes, status)
     assert saw_wide
     ann.close()
+
+
+def test_benchmark_batch_slice_equals_oracle(pa, oracle):
+    """200 of the benchmark's synthetic 50 kb contigs in one batch (the wavefront kernel's normal load: step-backs, helper
+    lanes, spill lists all occur): every gene list equals the oracle's.  (`tools/validate_batch.py` does all 1000.)"""
+    seqs = [pa.synth_contig(i, 50000) for i in range(0, 1000, 5)]
+    ann = pa.Annotator()
+    res = ann.annotate(seqs)
+    assert all(ann.globals(i).sssp_kernel == 2 for i in range(len(seqs)))
+    for s, (status, genes) in zip(seqs, res):
+        o = oracle.run(s)
+        assert status == o["status"] == 0
+        assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"])
+        assert np.array_equal(genes["strand"], o["gene_strand"])
+        np.testing.assert_allclose(genes["score"], o["gene_score"], rtol=WTOL)
+    ann.close()
