@@ -77,7 +77,7 @@ struct phx_ctx {
     DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
-    DevBuf b_node, b_parent, b_inoff, b_no, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -235,6 +235,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
     for (const DevBuf *q : {&c->b_parent, &c->b_path}) v = std::min(v, cap_of(*q, 4, 8));
     v = std::min(v, cap_of(c->b_no, 8, 8));
+    v = std::min(v, cap_of(c->b_ehit, 8, 8));
     v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
     v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
     k->node = v;
@@ -261,6 +262,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
     b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
+    b->ehit = (uint64_t *)c->b_ehit.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
@@ -424,7 +426,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -534,6 +536,7 @@ int run_once(phx_ctx *c, bool learn) {
             if ((rc = ensure(c, *q, NV * 4))) return rc;
         if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
         if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
+        if ((rc = ensure(c, c->b_ehit, NV * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)std::max(c->n_limbs, 2)))) return rc;
         HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s)); // the offsets stand; the capacities are now sufficient
     }

@@ -172,6 +172,7 @@ struct DBatch {
     int32_t *parent;
     uint32_t *in_off;
     double *no;
+    uint64_t *ehit;     // per node: verdicts of its first 64 overlap-edge candidates (k_edges<false> -> k_edges<true>)
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
