@@ -77,7 +77,7 @@ struct phx_ctx {
     DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0;
     int64_t tot_words = 0, tot_items = 0;
-    DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -233,7 +233,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     k->orf = cap_of(c->b_orf, sizeof(DOrf), 1);
     k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, sizeof(DGene), 1));
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
-    for (const DevBuf *q : {&c->b_parent, &c->b_path}) v = std::min(v, cap_of(*q, 4, 8));
+    for (const DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist}) v = std::min(v, cap_of(*q, 4, 8));
     v = std::min(v, cap_of(c->b_no, 8, 8));
     v = std::min(v, cap_of(c->b_ehit, 8, 8));
     v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
@@ -263,6 +263,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
     b->ehit = (uint64_t *)c->b_ehit.p;
+    b->olist = (int32_t *)c->b_olist.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
@@ -426,7 +427,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
@@ -532,7 +533,7 @@ int run_once(phx_ctx *c, bool learn) {
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
         if ((rc = ensure(c, c->b_genes, sizeof(DGene) * G))) return rc;
         if ((rc = ensure(c, c->b_node, NV * sizeof(DNode)))) return rc;
-        for (DevBuf *q : {&c->b_parent, &c->b_path})
+        for (DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist})
             if ((rc = ensure(c, *q, NV * 4))) return rc;
         if ((rc = ensure(c, c->b_inoff, (NV + (size_t)n + 1) * 4))) return rc;
         if ((rc = ensure(c, c->b_no, NV * 8))) return rc;

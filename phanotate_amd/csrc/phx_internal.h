@@ -110,6 +110,8 @@ struct DMeta { // one per contig
     int32_t sssp_iters;
     int32_t sssp_why;  // why k_sssp_wave handed the contig back: 1 window limits, 2 spill list, 3 no convergence, 4 too many step-backs (0: it did not)
     int32_t sssp_mode; // 0 = global-memory kernel, 1 = workgroup-per-contig LDS kernel, 2 = wavefront-per-contig kernel
+    int32_t n_open;    // entries of olist that are open nodes (incl. the target); the close nodes follow
+    int32_t pad4;
     double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
 };
 
@@ -172,6 +174,7 @@ struct DBatch {
     int32_t *parent;
     uint32_t *in_off;
     double *no;
+    int32_t *olist;     // per contig V-1 node ids: open nodes, the target, close nodes (k_node_order -> k_edges)
     uint64_t *ehit;     // per node: verdicts of its first 64 overlap-edge candidates (k_edges<false> -> k_edges<true>)
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)

@@ -133,6 +133,7 @@ void phxk_nodes(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_order, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_count(const DBatch *b, void *stream) {
