@@ -567,3 +567,31 @@ def test_benchmark_batch_slice_equals_oracle(pa, oracle):
         assert np.array_equal(genes["strand"], o["gene_strand"])
         np.testing.assert_allclose(genes["score"], o["gene_score"], rtol=WTOL)
     ann.close()
+
+
+def test_cabi_annotate_and_struct_download(pa, oracle):
+    """The one-call entry point of the C-ABI (phx_annotate -> phx_result[] with library-owned gene arrays, released by
+    phx_free_results), called the way INTEGRATION.md's ctypes stub does, equals the flat download and the oracle."""
+    import ctypes as C
+    from phanotate_amd import _lib
+    L = _lib.lib()
+    seqs = [pa.synth_contig(40 + i, 9000) for i in range(3)] + [b"acgtnnacgt" * 30, b"acg"]
+    ann = pa.Annotator()
+    flat = ann.annotate(seqs)
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*seqs)
+    lens = (C.c_int64 * n)(*[len(s) for s in seqs])
+    res = (_lib.Result * n)()
+    assert L.phx_annotate(ann.h, n, arr, lens, res) == 0
+    for i in range(n):
+        st, genes = flat[i]
+        assert res[i].status == st and res[i].n_genes == len(genes)
+        for k in range(res[i].n_genes):
+            g = res[i].genes[k]
+            assert (g.left, g.right, g.strand, g.frame, g.score) == (genes["left"][k], genes["right"][k], genes["strand"][k], genes["frame"][k], genes["score"][k])
+        o = oracle.run(seqs[i])
+        assert st == o["status"]
+        if st >= 0:
+            assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"])
+    L.phx_free_results(res, n)
+    ann.close()
