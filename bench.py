@@ -108,16 +108,25 @@ def main():
 
     for _ in range(args.warmup):
         ann.run()
+    # untimed pass with every stage bracketed by HIP events: the stage table, and which kernel dominates
     ann.set_profiling(True)
     ann.stage_ms(reset=True)
+    for _ in range(3):
+        ann.run()
+    stages_all = ann.stage_ms(reset=True)
+    kern = {k: v for k, v in stages_all.items() if k not in ("copies", "memset") and v[1] > 0}
+    dom = max(kern, key=lambda k: kern[k][0])
+    # timed region: K steps; only the dominant stage keeps its two HIP events (on the launch stream), the rest of the
+    # run is enqueued without any (a full set of stage events costs 3 % of the step)
+    ann.set_profiling_stages([dom])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ann.run()
     barrier()
     dt = time.perf_counter() - t0
+    dom_total, dom_n = ann.stage_ms(reset=True)[dom]
     ann.set_profiling(False)
-    stages = ann.stage_ms(reset=True)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -127,9 +136,7 @@ def main():
     value = bp_total * args.steps / dt / 1e6
 
     if rank == 0:
-        kernels = {k: v for k, v in stages.items() if k not in ("copies", "memset") and v[1] > 0}
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        dom_ms = kernels[dom][0] / kernels[dom][1]
+        dom_ms = dom_total / max(dom_n, 1)
         balgo = algorithmic_bytes(sz)
         achieved = balgo / (dom_ms * 1e-3) / 1e9
         out = {
@@ -165,7 +172,7 @@ def main():
                 "algorithmic_bytes_per_launch": int(balgo),
                 "avg_launch_ms": round(dom_ms, 4),
             },
-            "stage_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[1] > 0},
+            "stage_ms_per_step": {k: round(v[0] / 3, 4) for k, v in stages_all.items() if v[1] > 0},
             "pcie_inclusive_Mbp_s": round(float(sz["L"]) / t_e2e / 1e6, 3),
         }
         if not args.no_cpu and world == 1:

@@ -116,6 +116,7 @@ def lib():
         "phx_tap_path": (C.c_int, [vp, i32, vp, i32, P(i32), vp, i32]),
         "phx_solve": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, P(i32), vp]),
         "phx_set_profiling": (C.c_int, [vp, C.c_int]),
+        "phx_set_profiling_stages": (C.c_int, [vp, C.c_uint32]),
         "phx_get_stage_ms": (C.c_int, [vp, P(C.c_float), P(i32), C.c_int]),
         "phx_stage_name": (C.c_char_p, [C.c_int]),
         "phx_batch_sizes": (C.c_int, [vp, P(i64), P(i64), P(i64), P(i64)]),
@@ -133,5 +134,5 @@ def lib():
 
 EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_destroy",
            "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_run", "phx_download", "phx_download_flat", "phx_tap_globals",
-           "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_solve", "phx_set_profiling",
+           "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
            "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table"]

@@ -191,6 +191,14 @@ class Annotator:
     def set_profiling(self, on=True):
         self._chk(self.L.phx_set_profiling(self.h, 1 if on else 0), "phx_set_profiling")
 
+    def set_profiling_stages(self, names):
+        """Bracket only the named stages with events (two events per run for one stage); [] switches profiling off."""
+        idx = {self.L.phx_stage_name(k).decode(): k for k in range(_lib.N_STAGES)}
+        mask = 0
+        for nm in names:
+            mask |= 1 << idx[nm]
+        self._chk(self.L.phx_set_profiling_stages(self.h, mask), "phx_set_profiling_stages")
+
     def stage_ms(self, reset=True):
         ms = (C.c_float * _lib.N_STAGES)()
         nl = (C.c_int32 * _lib.N_STAGES)()

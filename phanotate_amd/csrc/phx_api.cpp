@@ -83,11 +83,17 @@ struct phx_ctx {
     int last_mask = 0;
     int64_t last_lds[4] = {0, 0, 0, 0};
     int64_t max_len = 0;
+    // steady-state runs replay a captured HIP graph of the whole enqueue (valid while batch layout, buffers and solver classes stand)
+    bool graphs_enabled = true, graph_valid = false, tiles_dirty = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_flags = -1;
     void *h_stage = nullptr; // pinned staging for H2D of ASCII
     size_t h_stage_cap = 0;
     std::vector<DGene> h_genes;
     // profiling
     bool prof = false;
+    uint32_t prof_mask = 0xffffffffu; // stages that are bracketed by events when prof is on
     bool force_global_sssp = false; // test hook: run every contig through the global-memory SSSP kernel
     float stage_ms[PHX_N_STAGES] = {0};
     int stage_n[PHX_N_STAGES] = {0};
@@ -109,6 +115,7 @@ namespace {
 int ensure(phx_ctx *c, DevBuf &b, size_t bytes) {
     // 2 KB of slack behind every array: the staging loads of k_sssp_wave read whole 16-byte / 256-node groups
     if (bytes + 2048 <= b.cap && b.p) return PHX_OK;
+    c->graph_valid = false; // a buffer moves: the captured graph holds stale pointers
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     size_t want = bytes + bytes / 8 + 4096;
@@ -204,12 +211,13 @@ hipEvent_t get_event(phx_ctx *c) {
     return e;
 }
 struct StageTimer {
-    phx_ctx *c; int st; hipEvent_t a = nullptr, b = nullptr;
+    phx_ctx *c; int st; bool on = false; hipEvent_t a = nullptr, b = nullptr;
     StageTimer(phx_ctx *c_, int st_) : c(c_), st(st_) {
-        if (c->prof) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        on = c->prof && ((c->prof_mask >> st_) & 1u);
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
     }
     ~StageTimer() {
-        if (c->prof) { (void)hipEventRecord(b, c->stream); c->pending.push_back({st, {a, b}}); }
+        if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({st, {a, b}}); }
     }
 };
 void collect_timers(phx_ctx *c) {
@@ -277,6 +285,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->n = n;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
+    c->graph_valid = false; c->tiles_dirty = true;
     c->max_len = 0;
     int64_t off = 0, words = 0, items = 0, nbw = 0;
     for (int i = 0; i < n; i++) {
@@ -385,6 +394,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
     c->device = device;
     c->params = *params;
     c->force_global_sssp = getenv("PHX_FORCE_GLOBAL_SSSP") != nullptr; // test hook
+    c->graphs_enabled = getenv("PHX_NO_GRAPH") == nullptr;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
@@ -429,6 +439,8 @@ void phx_destroy(phx_ctx *c) {
     DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_t6) (void)hipFree(c->d_t6);
@@ -494,19 +506,13 @@ const int kRetry = 1000; // run_once: a buffer was too small for this batch (or 
 // from them (two extra host round trips: first run of a context, or a batch that outgrew it).  Otherwise everything is
 // enqueued at once against the buffers the context already has; the layout kernels flag a batch that does not fit, later
 // kernels then do nothing, and the caller runs again with `learn`.
-int run_once(phx_ctx *c, bool learn) {
+// Everything a run puts on the stream(s), from the accumulator resets to the copies of the results.  With `learn` it
+// stops twice to read the device-side totals and size the buffers; otherwise it only enqueues (and can be captured
+// into a HIP graph).  mask / lds: solver classes launched and the LDS given to k_sssp_lds per limb class.
+int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     int rc;
     const int n = c->n;
     hipStream_t s = c->stream;
-    if ((rc = ensure_position_buffers(c))) return rc;
-    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
-    if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
-    // reset per-contig accumulators (offsets and lengths stay)
-    for (DMeta &m : c->meta) {
-        DMeta k = m;
-        memset(&m, 0, sizeof(m));
-        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
-    }
     DBatch b;
     {
         StageTimer t(c, ST_MEMSET);
@@ -517,7 +523,6 @@ int run_once(phx_ctx *c, bool learn) {
     {
         StageTimer t(c, ST_COPY);
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
@@ -549,8 +554,8 @@ int run_once(phx_ctx *c, bool learn) {
     { StageTimer t(c, ST_NODES); phxk_nodes(&b, s); }
     { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); phxk_layout2(&b, s); }
     HIPCHK(c, hipGetLastError());
-    int mask = c->last_mask;
-    int64_t lds[4] = {c->last_lds[0], c->last_lds[1], c->last_lds[2], c->last_lds[3]};
+    mask = c->last_mask;
+    for (int k = 0; k < 4; k++) lds[k] = c->last_lds[k];
     int64_t n_edges = b.caps.edge;
     if (learn) { // sync #2: edge total, widest integer class, solver classes
         { StageTimer t(c, ST_COPY); HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s)); }
@@ -595,20 +600,87 @@ int run_once(phx_ctx *c, bool learn) {
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
     }
     HIPCHK(c, hipGetLastError());
-    { // final sync: per-contig records (statuses, offsets, gene counts) and the totals
+    { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
         HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s));
     }
+    return PHX_OK;
+}
+
+void drop_graph(phx_ctx *c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    c->graph_exec = nullptr; c->graph = nullptr; c->graph_valid = false;
+}
+
+// One pass over the whole path.  `learn`: read the device-side totals back after each layout kernel and size the buffers
+// from them (two extra host round trips: first run of a context, or a batch that outgrew it).  Otherwise everything is
+// enqueued at once against the buffers the context already has — as one HIP graph launch when the previous run's graph
+// still applies (same batch layout, buffers, solver classes) —; the layout kernels flag a batch that does not fit,
+// later kernels then do nothing, and the caller runs again with `learn`.
+int run_once(phx_ctx *c, bool learn) {
+    int rc;
+    hipStream_t s = c->stream;
+    if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
+    if ((rc = ensure_position_buffers(c))) return rc;
+    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
+    if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
+    // reset per-contig accumulators (offsets and lengths stay)
+    for (DMeta &m : c->meta) {
+        DMeta k = m;
+        memset(&m, 0, sizeof(m));
+        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
+    }
+    if (c->tiles_dirty) { // once per batch layout
+        HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s)); // c->tiles is pageable host memory
+        c->tiles_dirty = false;
+    }
+    int mask = 0;
+    int64_t lds[4] = {0, 0, 0, 0};
+    DCaps caps_now;
+    current_caps(c, &caps_now);
+    const bool use_graph = !learn && !c->prof && c->graphs_enabled;
+    bool launched = false;
+    if (use_graph) {
+        if (c->graph_valid && c->graph_exec && c->graph_flags == caps_now.flags) {
+            mask = c->last_mask;
+            for (int k = 0; k < 4; k++) lds[k] = c->last_lds[k];
+            if (hipGraphLaunch(c->graph_exec, s) == hipSuccess) launched = true;
+            else { (void)hipGetLastError(); drop_graph(c); c->graphs_enabled = false; }
+        } else {
+            drop_graph(c);
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                rc = enqueue_run(c, false, mask, lds);
+                hipGraph_t g = nullptr;
+                const hipError_t ee = hipStreamEndCapture(s, &g);
+                if (rc == PHX_OK && ee == hipSuccess && g && hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0) == hipSuccess &&
+                    hipGraphLaunch(c->graph_exec, s) == hipSuccess) {
+                    c->graph = g; c->graph_valid = true; c->graph_flags = caps_now.flags;
+                    launched = true;
+                } else {
+                    (void)hipGetLastError();
+                    if (g) (void)hipGraphDestroy(g);
+                    drop_graph(c);
+                    c->graphs_enabled = false; // this runtime cannot capture the run: enqueue directly from now on
+                }
+            } else { (void)hipGetLastError(); c->graphs_enabled = false; }
+        }
+    }
+    if (!launched && (rc = enqueue_run(c, learn, mask, lds))) return rc;
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
-    if (ht->overflow) return kRetry;
+    const DTotals *ht = c->h_tot;
+    if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = (ht->class_mask & ~mask) == 0;
     for (int k = 0; k < 4; k++) covered = covered && ht->lds_need[k] <= lds[k];
-    if (!covered) { c->last_mask = ht->class_mask; for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k]; return kRetry; }
-    c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
+    if (ht->class_mask != c->last_mask || ht->lds_need[0] != c->last_lds[0] || ht->lds_need[1] != c->last_lds[1] || ht->lds_need[2] != c->last_lds[2] || ht->lds_need[3] != c->last_lds[3])
+        c->graph_valid = false; // the next run launches other solver kernels / LDS sizes
     c->last_mask = ht->class_mask;
     for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k];
+    if (!covered) return kRetry;
+    c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
     c->have_plan = true;
     return PHX_OK;
 }
@@ -999,6 +1071,13 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
 int phx_set_profiling(phx_ctx *c, int on) {
     if (!c) return PHX_E_ARG;
     c->prof = on != 0;
+    c->prof_mask = 0xffffffffu;
+    return PHX_OK;
+}
+int phx_set_profiling_stages(phx_ctx *c, uint32_t stage_mask) {
+    if (!c) return PHX_E_ARG;
+    c->prof = stage_mask != 0;
+    c->prof_mask = stage_mask;
     return PHX_OK;
 }
 int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
