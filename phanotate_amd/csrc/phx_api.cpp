@@ -74,8 +74,8 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
-    int64_t tot_nbits = 0;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
+    int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
@@ -266,6 +266,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
+    b->bridge = (DBridge *)c->b_bridge.p;
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
     b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
     b->in_off = (uint32_t *)c->b_inoff.p;
@@ -287,7 +288,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->tiles.clear();
     c->graph_valid = false; c->tiles_dirty = true;
     c->max_len = 0;
-    int64_t off = 0, words = 0, items = 0, nbw = 0;
+    int64_t off = 0, words = 0, items = 0, nbw = 0, nbr = 0;
     for (int i = 0; i < n; i++) {
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
@@ -300,12 +301,14 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) { c->tiles.push_back(DTile{i, (int32_t)p0}); nt++; }
         m.nw = 8 * nt; // every feature tile writes 8 words per (class, frame)
         m.bits_off = words; m.item_off = items; m.nbits_off = nbw;
+        m.bridge_off = nbr; m.bridge_cap = (int32_t)(L / 500 + 2);
+        nbr += m.bridge_cap;
         nbw += 9 * (int64_t)m.nw;
         words += PHX_BITMAP_WORDS_PER_NW * (int64_t)m.nw; items += 6 * (int64_t)m.nw;
         off += L;
         off = (off + 15) & ~(int64_t)15; // 16-byte aligned rows let the feature kernel store uint4
     }
-    c->tot_words = words; c->tot_items = items; c->tot_nbits = nbw;
+    c->tot_words = words; c->tot_items = items; c->tot_nbits = nbw; c->tot_bridge = nbr;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
     c->uploaded = true;
     c->ran = false;
@@ -324,6 +327,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
     if ((rc = ensure(c, c->b_item, (size_t)(c->tot_items + 8) * 8))) return rc;
+    if ((rc = ensure(c, c->b_bridge, (size_t)(c->tot_bridge + 8) * sizeof(DBridge)))) return rc;
     return PHX_OK;
 }
 
@@ -436,7 +440,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -631,6 +635,7 @@ int run_once(phx_ctx *c, bool learn) {
         DMeta k = m;
         memset(&m, 0, sizeof(m));
         m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
+        m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
     }
     if (c->tiles_dirty) { // once per batch layout
         HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));

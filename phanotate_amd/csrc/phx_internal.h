@@ -18,7 +18,6 @@
 #define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
-#define PHX_MAX_BRIDGE 16
 #define PHX_N_CODON_BITMAPS 12 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple
 #define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
 
@@ -93,7 +92,9 @@ struct DMeta { // one per contig
     int64_t node_off, edge_off;
     int32_t n_bridge;
     int32_t maxexp; // max binary exponent of |trunc(w*1000)| over the ORF edges
-    DBridge bridge[PHX_MAX_BRIDGE];
+    int64_t bridge_off;  // this contig's slice of DBatch.bridge (layout, set on the host)
+    int32_t bridge_cap;  // = L/500 + 2: a bridge needs more than 500 uncovered bases
+    int32_t pad5;
     int32_t n_genes;
     int32_t n_path;
     int64_t gene_off;
@@ -166,6 +167,7 @@ struct DBatch {
     uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); zeroed every run
     uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
+    DBridge *bridge;    // per contig bridge_cap entries: the uncovered runs of functions.py:334 (k_node_rank -> k_edges)
     // per ORF / group
     DOrf *orf;
     DGrp *grp;

@@ -595,3 +595,17 @@ def test_cabi_annotate_and_struct_download(pa, oracle):
             assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"])
     L.phx_free_results(res, n)
     ann.close()
+
+
+def test_many_uncovered_runs_bridges(pa, oracle):
+    """Forty coding islands separated by 720 bp stop-rich spacers: every spacer is an uncovered run of more than 500 bases
+    and gets its bridge edges (functions.py:334-354); far more than the 16 an earlier fixed-size table held."""
+    spacer = "".join("tagctaactgattaa"[i % 15] for i in range(720))  # stop codons in all six frames every 15 bp
+    seq = spacer.join(pa.synth_contig(300 + i, 1500).decode() for i in range(40))
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    o = oracle.run(seq)
+    assert o["status"] == 0 and status == 0
+    assert ann.globals(0).n_bridge > 16
+    check_contig(ann, 0, seq, o, genes, status)
+    ann.close()
