@@ -120,7 +120,8 @@ typedef struct phx_globals {
     int32_t sssp_iters;  /* relaxation rounds summed over all windows and sweeps */
     int32_t status;
     int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig */
-    int32_t sssp_handed_back; /* 1: the wavefront kernel passed the contig on (spill list / window limits) */
+    int32_t sssp_handed_back; /* != 0: the wavefront kernel passed the contig on: 1 a node's 500 bp neighbourhood exceeds a window,
+                               * 2 spill list full, 3 no convergence, 4 too many step-backs */
 } phx_globals;
 
 /* ---- library ---- */

@@ -845,7 +845,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->sssp_sweeps = m.sweeps;
     out->sssp_iters = m.sssp_iters;
     out->sssp_kernel = m.sssp_mode;
-    out->sssp_handed_back = m.sssp_why > 0 ? 1 : 0;
+    out->sssp_handed_back = m.sssp_why > 0 ? m.sssp_why : 0;
     return PHX_OK;
 }
 

@@ -516,7 +516,7 @@ def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, exp
         assert gl.sssp_kernel == 2 and gl.sssp_handed_back == 0
     else:
         assert deg.max() > 64 * 4 + 512  # ... and more than the spill list holds
-        assert gl.sssp_kernel == 1 and gl.sssp_handed_back == 1
+        assert gl.sssp_kernel == 1 and gl.sssp_handed_back in (1, 2)  # window limits (the stop node alone exceeds the staged in-edges) or spill list
     dist, want = _py_bellman_ford_genes(o)
     assert [(int(g["left"]), int(g["right"])) for g in genes] == want
     p, d = ann.path(0)

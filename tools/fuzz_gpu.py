@@ -52,7 +52,7 @@ def main():
     seqs = [make(rng) for _ in range(n)]
     import phanotate_amd as pa
     ann = pa.Annotator()
-    bad = 0; ties = 0; kern = {}; back = 0; skipped = 0
+    bad = 0; ties = 0; kern = {}; back = 0; skipped = 0; why = {}
     with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
         want = list(ex.map(orc, seqs, chunksize=4))
     for b0 in range(0, n, 100):
@@ -61,7 +61,8 @@ def main():
         for i, (status, genes) in enumerate(res):
             g = ann.globals(i)
             if g.n_node > 2 and status >= 0: kern[(g.n_limbs, g.sssp_kernel)] = kern.get((g.n_limbs, g.sssp_kernel), 0) + 1
-            back += g.sssp_handed_back
+            back += 1 if g.sssp_handed_back else 0
+            why[g.sssp_handed_back] = why.get(g.sssp_handed_back, 0) + (1 if g.sssp_handed_back else 0)
             st, exp = want[b0 + i]
             if exp is None: skipped += 1; continue
             ok = (status == st) if st < 0 else (status >= 0 and [int(x) for x in genes["left"]] == exp[0] and [int(x) for x in genes["right"]] == exp[1] and [int(x) for x in genes["strand"]] == exp[2])
@@ -71,7 +72,7 @@ def main():
             if not ok:
                 bad += 1
                 if bad <= 5: print("MISMATCH contig %d (len %d): status %d vs %d, %d vs %d genes" % (b0 + i, len(part[i]), status, st, len(genes), len(exp[0])))
-    print("fuzz seed %d: %d contigs, %d mismatches, %d equal-length ties resolved differently, %d beyond the oracle's integers; (limbs, kernel) counts %s; handed back %d" % (seed, n, bad, ties, skipped, kern, back))
+    print("fuzz seed %d: %d contigs, %d mismatches, %d equal-length ties resolved differently, %d beyond the oracle's integers; (limbs, kernel) counts %s; handed back %d (by reason %s)" % (seed, n, bad, ties, skipped, kern, back, {k: v for k, v in why.items() if k}))
     return 1 if bad else 0
 
 if __name__ == "__main__":
