@@ -489,13 +489,13 @@ def test_large_contig_beyond_lds_parent_table(pa, oracle):
     ann.close()
 
 
-@pytest.mark.parametrize("ncodons,p_gtg,expect", [(3000, 0.12, "wave"), (3500, 0.20, "wave"), (4000, 0.45, "handed_back")])
+@pytest.mark.parametrize("ncodons,p_gtg,expect", [(3000, 0.12, "wave"), (3500, 0.20, "wave"), (5500, 0.27, "handed_back"), (4000, 0.45, "dense")])
 def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, expect):
     """A 9-12 kb reading frame in a GC-rich contig: p_stop is small, so the path sums still fit 128 bits and the contig
     goes to the wavefront-per-contig kernel.  The ORF's start nodes lie further back than its LDS distance ring holds
     (sources folded in from global memory), and its stop node has hundreds of in-edges (one per in-frame gtg): more than
-    a wavefront's lanes (helper lanes + spill list) and, in the last case, more than the spill list takes, so that the
-    contig is handed to the workgroup kernel.  Genes must equal the exact solution of the oracle's graph either way."""
+    a wavefront's lanes (helper lanes + spill list); with more than 1280 the contig is handed to the workgroup kernel when
+    the sweep reaches the stop node, and a contig with more than ~60 open nodes per 500 bp is routed there from the start.  Genes must equal the exact solution of the oracle's graph either way."""
     rng = np.random.RandomState(7)
     def gc_rich(n):
         return "".join(rng.choice(list("acgt"), n, p=[0.1, 0.4, 0.4, 0.1]))
@@ -514,9 +514,13 @@ def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, exp
     assert deg.max() > 64 * 4  # the stop node needs more than 64 lanes of 4 in-edges
     if expect == "wave":
         assert gl.sssp_kernel == 2 and gl.sssp_handed_back == 0
+    elif expect == "handed_back":
+        assert deg.max() > 1280  # ... and more than a window's staging area: the wavefront kernel passes the contig on when it gets there
+        assert gl.sssp_kernel == 1 and gl.sssp_handed_back in (1, 2)
     else:
-        assert deg.max() > 64 * 4 + 512  # ... and more than the spill list holds
-        assert gl.sssp_kernel == 1 and gl.sssp_handed_back in (1, 2)  # window limits (the stop node alone exceeds the staged in-edges) or spill list
+        # so many starts that more than 64 open nodes fall within 500 bp: k_edges<false> flags the contig and it never
+        # enters the wavefront kernel
+        assert gl.sssp_kernel == 1 and gl.sssp_handed_back == 0
     dist, want = _py_bellman_ford_genes(o)
     assert [(int(g["left"]), int(g["right"])) for g in genes] == want
     p, d = ann.path(0)
