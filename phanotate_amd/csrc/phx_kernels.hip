@@ -124,7 +124,7 @@ extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
     if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
 }
-void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b); }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, 6), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_train(const DBatch *, void *) {}
