@@ -587,21 +587,35 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         int nlaunch = 0, nclass = 0;
         bool used[3] = {false, false, false};
         for (int k = 0; k < 4; k++) nclass += ((mask >> (4 * k)) & 7) ? 1 : 0;
-        if (nclass > 1 && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
+        // contigs of the 128-bit class that never enter the wavefront kernel (too dense for its windows) are solved by the
+        // workgroup kernel on a side stream, beside the wavefront kernel; the launch after the wavefront kernel then only
+        // takes what that kernel handed back
+        const bool early = ((mask >> 2) & 1) && ((mask >> 16) & 1) && c->aux[2];
+        if ((nclass > 1 || early) && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
+        if (early) {
+            HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork, 0));
+            used[2] = true;
+            phxk_sssp(&b, 2, 1, (size_t)lds[0], c->aux[2]);
+            HIPCHK(c, hipEventRecord(c->ev_join[2], c->aux[2]));
+        }
         for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
             if (!((mask >> (4 * k)) & 7)) continue;
             hipStream_t st = s;
             if (nlaunch > 0 && c->aux[0]) {
-                const int a = (nlaunch - 1) % 3;
+                const int a = (nlaunch - 1) % 2;
                 if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
                 st = c->aux[a];
             }
             for (int mode = 2; mode >= 0; mode--)
-                if ((mask >> (4 * k + mode)) & 1) phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
+                if ((mask >> (4 * k + mode)) & 1) {
+                    if (early && k == 0 && mode == 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launch: it skips what that one solved
+                    phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
+                }
             nlaunch++;
         }
-        for (int a = 0; a < 3; a++)
+        for (int a = 0; a < 2; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
+        if (early) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
     }
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals

@@ -140,7 +140,8 @@ struct DNode {
 struct DTotals {
     int64_t orf, grp, node, cb, edge; // totals over the batch
     int32_t nlmax;       // widest integer class (64-bit limbs) any contig needs
-    int32_t class_mask;  // bit 4*k + mode: some contig wants limb class k (2,4,8,17 limbs) solved by kernel `mode`
+    int32_t class_mask;  // bit 4*k + mode: some contig wants limb class k (2,4,8,17 limbs) solved by kernel `mode`;
+                         // bit 16 + k: class k has contigs that were routed to the workgroup kernel from the start (dense)
     int32_t vmax;        // largest node count
     int32_t overflow;    // bit 0: ORF/node buffers, bit 1: edge/distance buffers too small -> the later kernels do nothing
     int64_t lds_need[4]; // per limb class: dynamic LDS k_sssp_lds needs (max over the contigs it may get)
