@@ -2,12 +2,13 @@
 """CPU prototype of the single-wavefront SSSP schedule (window = ADV advance nodes + 500 bp look-ahead,
 A/B phases, rollback when a close node near the window start changes).  Checks distances/paths against the
 oracle and reports rounds per window and rollback rates.  Development tool, not part of the product."""
-import sys, ctypes as C
-sys.path.insert(0, '/root/repo')
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle
 
-lib = C.CDLL('/root/repo/phanotate_amd/libphx.so')
+lib = C.CDLL(os.path.join(ROOT, 'phanotate_amd', 'libphx.so'))
 def synth(seed, L):
     b = C.create_string_buffer(L); lib.phx_synth_contig(C.c_uint64(seed), C.c_int64(L), b); return b.raw[:L].decode()
 
