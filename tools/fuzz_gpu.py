@@ -12,7 +12,7 @@ def make(rng):
     gc = rng.uniform(0.2, 0.8)
     p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]
     s = rng.choice(list("acgt"), L, p=p)
-    kind = rng.randint(8)
+    kind = rng.randint(9)
     def put(at, text):
         text = text[: max(0, L - at)]
         s[at:at + len(text)] = list(text)
@@ -34,6 +34,13 @@ def make(rng):
     elif kind == 6:  # GC-rich long open frames
         n = int(rng.randint(500, 3000))
         put(int(rng.randint(0, max(1, L - 3 * n))), "atg" + "".join(rng.choice(["gcc", "ggc", "gtg", "cgc", "ccg", "gcg"], n)) + "tga")
+    elif kind == 7:  # starts of both strands mixed into stop-free frames: many close AND open nodes within 500 bp
+        for _ in range(int(rng.randint(1, 4))):
+            n = int(rng.randint(150, 900))
+            q = rng.uniform(0.03, 0.2)
+            cod = ["atg", "gtg", "ttg", "cat", "cac", "caa", "gcc", "gac", "ctc", "aaa", "ggc", "acg"]
+            pr = [q / 3] * 6 + [(1 - 2 * q) / 6] * 6
+            put(3 * int(rng.randint(0, max(1, (L - 3 * n) // 3))), "".join(rng.choice(cod, n, p=pr)))
     seq = "".join(s)
     if rng.rand() < 0.2: seq = seq.upper()
     return seq
