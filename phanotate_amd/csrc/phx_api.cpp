@@ -58,8 +58,8 @@ struct phx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr}; // side streams so that independent SSSP classes overlap
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // side streams: independent SSSP classes overlap (0..2); k_wave_plan beside k_edges<true> (3)
+    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -77,6 +77,7 @@ struct phx_ctx {
     DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
+    DevBuf b_win, b_wrole;
     DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
@@ -248,6 +249,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
     k->node = v;
     k->cb = cap_of(c->b_cbits, 8, 8);
+    k->win = std::min(cap_of(c->b_win, sizeof(DWin), 8), cap_of(c->b_wrole, sizeof(uint2) * WIN_ROLES, 8));
     k->edge = std::min(cap_of(c->b_esrc, 4, 1), cap_of(c->b_ew, 8, 1));
     k->limbs = limbs;
     k->flags = (c->force_global_sssp ? 1 : 0) | (getenv("PHX_SSSP_NOWAVE") ? 2 : 0);
@@ -273,6 +275,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->no = (double *)c->b_no.p;
     b->ehit = (uint64_t *)c->b_ehit.p;
     b->olist = (int32_t *)c->b_olist.p;
+    b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
@@ -406,9 +409,9 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         c->own_stream = true;
     }
-    for (int a = 0; a < 3; a++)
+    for (int a = 0; a < 4; a++)
         if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
@@ -440,7 +443,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -455,8 +458,9 @@ void phx_destroy(phx_ctx *c) {
     c->meta.release();
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    for (int a = 0; a < 3; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
+    for (int a = 0; a < 4; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -548,6 +552,9 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
         if ((rc = ensure(c, c->b_ehit, NV * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)std::max(c->n_limbs, 2)))) return rc;
+        const size_t NW = NV / 16 + 8 * (size_t)n + 16; // window records of k_sssp_wave, see k_layout1
+        if ((rc = ensure(c, c->b_win, NW * sizeof(DWin)))) return rc;
+        if ((rc = ensure(c, c->b_wrole, NW * sizeof(uint2) * WIN_ROLES))) return rc;
         HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s)); // the offsets stand; the capacities are now sufficient
     }
     fill_batch(c, &b);
@@ -574,6 +581,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         n_edges = ht->edge;
     }
     fill_batch(c, &b);
+    // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
+    HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
+    HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
+    phxk_wave_plan(&b, c->aux[3]);
+    HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
         StageTimer t(c, ST_EDGE_FILL);
@@ -583,6 +595,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
         StageTimer t(c, ST_SSSP);
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[3], 0)); // k_wave_plan: also decides which contigs the wavefront kernel takes
         const int nl_of[4] = {2, 4, 8, 17};
         int nlaunch = 0, nclass = 0;
         bool used[3] = {false, false, false};

@@ -94,7 +94,7 @@ struct DMeta { // one per contig
     int32_t maxexp; // max binary exponent of |trunc(w*1000)| over the ORF edges
     int64_t bridge_off;  // this contig's slice of DBatch.bridge (layout, set on the host)
     int32_t bridge_cap;  // = L/500 + 2: a bridge needs more than 500 uncovered bases
-    int32_t pad5;
+    int32_t n_win;       // windows k_wave_plan laid out for k_sssp_wave (its slice starts at win_off, see k_layout1)
     int32_t n_genes;
     int32_t n_path;
     int64_t gene_off;
@@ -114,6 +114,7 @@ struct DMeta { // one per contig
     int32_t n_open;    // entries of olist that are open nodes (incl. the target); the close nodes follow
     int32_t dense;     // some node has more than ~62 close / open nodes within the next 500 bp: k_sssp_wave's windows cannot take it (k_edges<false>)
     double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
+    int64_t win_off;   // first window record of this contig in DBatch.win (capacity n_node/16 + 7)
 };
 
 struct DTile {
@@ -135,6 +136,16 @@ struct DNode {
 };
 
 // Everything the kernels need, passed by value.
+// One window of k_sssp_wave's sweep (written by k_wave_plan): nodes [v0, v1) iterate, [v0, va) become final.
+struct DWin {
+    int32_t v0, va, v1;
+    uint32_t e0;     // first in-edge of v0 (contig-relative)
+    uint32_t ne;     // in-edges of [v0, v1)
+    uint32_t pa, pb; // phase A (close nodes) / B (open nodes): lanes in use | largest per-lane in-edge count << 8 | most helper lanes of a node << 16
+    uint32_t sp;     // spill entries of the window
+};
+#define WIN_ROLES 128 // lane records per window: 64 of phase A, 64 of phase B (uint2 each, see wv_role_pack)
+
 // Batch totals and decisions computed on the device (k_layout1 / k_layout2), so that a run needs no host round trip
 // when the buffers of the context are already large enough; the host reads them back with the final results.
 struct DTotals {
@@ -148,6 +159,7 @@ struct DTotals {
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
+    int64_t win;                      // window records (and WIN_ROLES lane records each)
     int32_t limbs;                    // 64-bit words per node in `dist`
     int32_t flags;                    // bit 0: force the global-memory solver, bit 1: keep contigs off the wavefront kernel
 };
@@ -177,6 +189,8 @@ struct DBatch {
     int32_t *parent;
     uint32_t *in_off;
     double *no;
+    DWin *win;          // k_wave_plan -> k_sssp_wave: window records,
+    uint2 *wrole;       //   WIN_ROLES lane records per window
     int32_t *olist;     // per contig V-1 node ids: open nodes, the target, close nodes (k_node_order -> k_edges)
     uint64_t *ehit;     // per node: verdicts of its first 64 overlap-edge candidates (k_edges<false> -> k_edges<true>)
     uint64_t *dist;
@@ -208,6 +222,7 @@ void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / grou
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
+void phxk_wave_plan(const DBatch *b, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 #ifdef __cplusplus

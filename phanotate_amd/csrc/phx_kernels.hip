@@ -162,6 +162,8 @@ void phxk_layout1(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout1,
 void phxk_layout2(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout2, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); }
 
 int phxk_sssp_wave_ok(int nl) { return nl == 2; }
+// windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges)
+void phxk_wave_plan(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_wave_plan, dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b); }
 
 // mode 0: global-memory kernel (+ k_path); mode 1: workgroup-per-contig LDS kernel with `lds_bytes` of dynamic LDS;
 // mode 2: wavefront-per-contig kernel (contigs it hands back carry their fallback mode in sssp_mode afterwards)
