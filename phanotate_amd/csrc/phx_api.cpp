@@ -59,7 +59,7 @@ struct phx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // side streams: independent SSSP classes overlap (0..2); k_wave_plan beside k_edges<true> (3)
-    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -411,7 +411,8 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
     }
     for (int a = 0; a < 4; a++)
         if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
@@ -461,6 +462,8 @@ void phx_destroy(phx_ctx *c) {
     for (int a = 0; a < 4; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
+    if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
+    if (c->ev_join_nodes) (void)hipEventDestroy(c->ev_join_nodes);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -560,9 +563,14 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     fill_batch(c, &b);
     HIPCHK(c, hipMemsetAsync(c->b_cbits.p, 0, (size_t)(b.caps.cb + 8) * 8, s));
     { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
+    // nodes (coverage, ranks, records, order) beside the ORF statistics: both only read what k_orf<true> wrote
+    HIPCHK(c, hipEventRecord(c->ev_fork_nodes, s));
+    HIPCHK(c, hipStreamWaitEvent(c->aux[1], c->ev_fork_nodes, 0));
+    phxk_nodes(&b, c->aux[1]);
+    HIPCHK(c, hipEventRecord(c->ev_join_nodes, c->aux[1]));
     { StageTimer t(c, ST_ORF_STATS); phxk_orf_stats(&b, s); }
     { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
-    { StageTimer t(c, ST_NODES); phxk_nodes(&b, s); }
+    { StageTimer t(c, ST_NODES); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_nodes, 0)); phxk_node_attr(&b, s); }
     { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); phxk_layout2(&b, s); }
     HIPCHK(c, hipGetLastError());
     mask = c->last_mask;

@@ -217,6 +217,7 @@ void phxk_orf_stats(const DBatch *b, void *stream);
 void phxk_train(const DBatch *b, void *stream);
 void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);
+void phxk_node_attr(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals

@@ -129,13 +129,16 @@ void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<tru
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_train(const DBatch *, void *) {}
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+// node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
+// beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_order, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
 }
+// part 2: other_end and the p_stop attribute of every node (reads DOrf.pstop of k_orf_stats)
+void phxk_node_attr(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
