@@ -13,7 +13,8 @@
 // edges            k_edges<FILL>, k_edges_scan,             phx_graph.inc      functions.py:334-354, 360-452
 //                  k_edge_weights
 // layout           k_layout1, k_layout2                     phx_layout.inc     (offsets, integer class and solver per contig)
-// shortest path    k_sssp_wave<2> (wavefront / contig)      phx_sssp_wave.inc  fastpathz (phanotate.py:56-64), exact NL x 64-bit
+// shortest path    k_wave_plan + k_sssp_wave<2> (wavefront  phx_sssp_wave.inc  fastpathz (phanotate.py:56-64), exact NL x 64-bit
+//                  / contig)
 //                  k_sssp_lds<NL> (workgroup / contig),     phx_sssp.inc       integers; path -> genes phanotate.py:65-76,
 //                  k_sssp<NL> + k_path<NL> (global memory)                     locus.py:29-37
 //
