@@ -755,6 +755,7 @@ int phx_run(phx_ctx *c) {
                     m.pmax[0] * 0.01, m.pmax[1] * 0.01, m.pmax[2] * 0.01, m.pmax[3] * 0.01, m.pmin[0] * 0.01, m.pmin[1] * 0.01);
             const DMeta &q = c->meta[tt[tt.size() / 2].second];
             fprintf(stderr, "  slowest contig: 64-bit phases %u (redone in 128 bits: %u), 128-bit phases %u, base moves %u; median contig: %u (%u), %u, %u\n", m.tr[0], m.tr[1], m.tr[2], m.tr[3], q.tr[0], q.tr[1], q.tr[2], q.tr[3]);
+            fprintf(stderr, "  median contig (-DWV_PROFILE_AB): helper-lane maxima summed over phases A %u B %u; phases with more than 4 helpers A %u B %u\n", q.tr[4], q.tr[5], q.tr[6], q.tr[7]);
             fprintf(stderr, "  median contig %d: phases %d: relax %.1f followers %.1f spill %.1f apply %.1f loop %.1f us | setup %.1f gather %.1f plan %.1f window-end %.1f path+genes %.1f\n", tt[tt.size() / 2].second, q.sssp_iters,
                     q.bg[0] * 0.01, q.bg[1] * 0.01, q.bg[2] * 0.01, q.bg[3] * 0.01, q.bg[4] * 0.01, q.pmax[1] * 0.01, q.pmax[2] * 0.01, q.pmax[3] * 0.01, q.pmin[1] * 0.01, q.bg[5] * 0.01);
         }
