@@ -78,6 +78,8 @@ struct phx_ctx {
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
+    DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
+    bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
@@ -289,7 +291,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->n = n;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
-    c->graph_valid = false; c->tiles_dirty = true;
+    c->graph_valid = false; c->tiles_dirty = true; c->meta0_dirty = true;
     c->max_len = 0;
     int64_t off = 0, words = 0, items = 0, nbw = 0, nbr = 0;
     for (int i = 0; i < n; i++) {
@@ -444,7 +446,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -533,7 +535,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     }
     {
         StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->meta.data(), sizeof(DMeta) * (size_t)n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToDevice, s)); // accumulators back to zero
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
@@ -665,12 +667,17 @@ int run_once(phx_ctx *c, bool learn) {
     if ((rc = ensure_position_buffers(c))) return rc;
     if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
     if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
-    // reset per-contig accumulators (offsets and lengths stay)
-    for (DMeta &m : c->meta) {
-        DMeta k = m;
-        memset(&m, 0, sizeof(m));
-        m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
-        m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
+    if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
+    if (c->meta0_dirty) { // once per batch layout: the records a run starts from (offsets and lengths set, accumulators zero)
+        for (DMeta &m : c->meta) {
+            DMeta k = m;
+            memset(&m, 0, sizeof(m));
+            m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
+            m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        c->meta0_dirty = false;
     }
     if (c->tiles_dirty) { // once per batch layout
         HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));
