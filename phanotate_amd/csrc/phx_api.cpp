@@ -18,8 +18,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_PATH, ST_COPY };
-const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "path", "copies"};
+enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_EDGE_WEIGHTS, ST_COPY };
+const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "edge_weights", "copies"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -598,8 +598,8 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
-        StageTimer t(c, ST_EDGE_FILL);
-        phxk_edges_fill(&b, n_edges, s);
+        { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+        { StageTimer t(c, ST_EDGE_WEIGHTS); phxk_edge_weights(&b, n_edges, s); }
     }
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the

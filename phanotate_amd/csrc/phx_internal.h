@@ -221,7 +221,8 @@ void phxk_node_attr(const DBatch *b, void *stream);
 void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
-void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream);
+void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for

@@ -144,8 +144,9 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_edges_fill(const DBatch *b, int64_t n_edges, void *stream) {
-    hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
+// the overlap weights k_edges<true> left pending
+void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream) {
     if (b->defer_overlap && n_edges > 0)
         hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + EW_T * EW_PER - 1) / (EW_T * EW_PER))), dim3(EW_T), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
 }
