@@ -80,6 +80,7 @@ struct phx_ctx {
     DevBuf b_win, b_wrole;
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
+    int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
     DevBuf b_node, b_parent, b_inoff, b_no, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
@@ -291,7 +292,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->n = n;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
-    c->graph_valid = false; c->tiles_dirty = true; c->meta0_dirty = true;
+    c->graph_valid = false; c->tiles_dirty = true; c->meta0_dirty = true; c->runs_on_layout = 0;
     c->max_len = 0;
     int64_t off = 0, words = 0, items = 0, nbw = 0, nbr = 0;
     for (int i = 0; i < n; i++) {
@@ -688,7 +689,9 @@ int run_once(phx_ctx *c, bool learn) {
     int64_t lds[4] = {0, 0, 0, 0};
     DCaps caps_now;
     current_caps(c, &caps_now);
-    const bool use_graph = !learn && !c->prof && c->graphs_enabled;
+    // capturing and instantiating a graph costs about 0.7 ms: it pays when the same batch layout is run again, not for a
+    // batch that is uploaded, run once and replaced (phx_annotate on fresh contigs)
+    const bool use_graph = !learn && !c->prof && c->graphs_enabled && (c->runs_on_layout >= 2 || c->graph_valid);
     bool launched = false;
     if (use_graph) {
         if (c->graph_valid && c->graph_exec && c->graph_flags == caps_now.flags) {
@@ -729,6 +732,7 @@ int run_once(phx_ctx *c, bool learn) {
     if (!covered) return kRetry;
     c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
     c->have_plan = true;
+    c->runs_on_layout++;
     return PHX_OK;
 }
 
