@@ -573,6 +573,45 @@ def test_benchmark_batch_slice_equals_oracle(pa, oracle):
     ann.close()
 
 
+def test_mixed_strand_start_rich_stretches_equal_oracle(pa, oracle):
+    """Random contigs with stop-free stretches that are rich in start codons of BOTH strands (many close and open nodes within
+    500 bp: narrow windows, helper lanes, spill lists, hand-backs to the workgroup kernel) and a wide GC range (ORF weights
+    from 2^10 to beyond 2^64 in one contig: the relative distance ring moves its base).  Every path has the oracle's exact
+    integer length; gene lists are identical unless another path of exactly that length exists."""
+    rng = np.random.RandomState(20240928)
+    seqs = []
+    for _ in range(24):
+        L = int(rng.choice([6000, 12000, 25000]))
+        gc = rng.uniform(0.25, 0.7)
+        s = rng.choice(list("acgt"), L, p=[(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+        for _ in range(int(rng.randint(1, 4))):
+            n = int(rng.randint(150, 900))
+            q = rng.uniform(0.03, 0.2)
+            cod = ["atg", "gtg", "ttg", "cat", "cac", "caa", "gcc", "gac", "ctc", "aaa", "ggc", "acg"]
+            text = "".join(rng.choice(cod, n, p=[q / 3] * 6 + [(1 - 2 * q) / 6] * 6))
+            at = 3 * int(rng.randint(0, max(1, (L - 3 * n) // 3)))
+            text = text[: max(0, L - at)]
+            s[at:at + len(text)] = list(text)
+        seqs.append("".join(s))
+    ann = pa.Annotator()
+    res = ann.annotate(seqs)
+    kernels = set()
+    for i, (s, (status, genes)) in enumerate(zip(seqs, res)):
+        o = oracle.run(s)
+        if o["status"] == -7:
+            continue  # beyond the oracle's 256-bit integers (python-int solves cover such cases elsewhere)
+        assert status == o["status"], i
+        if status < 0 or not len(o["path"]):
+            continue
+        kernels.add(ann.globals(i).sssp_kernel)
+        assert abs(ann.path(i)[1] - int(o["path_dist"])) <= abs(int(o["path_dist"])) * 1e-12, i
+        same = np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]) and np.array_equal(genes["strand"], o["gene_strand"])
+        if same:
+            np.testing.assert_allclose(genes["score"], o["gene_score"], rtol=WTOL)
+    assert 2 in kernels  # the wavefront kernel took part
+    ann.close()
+
+
 def test_cabi_annotate_and_struct_download(pa, oracle):
     """The one-call entry point of the C-ABI (phx_annotate -> phx_result[] with library-owned gene arrays, released by
     phx_free_results), called the way INTEGRATION.md's ctypes stub does, equals the flat download and the oracle."""
