@@ -517,10 +517,13 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)np]);
         for (int k = 0; k < np; k++) done[(size_t)k].store(0, std::memory_order_relaxed);
         std::vector<std::thread> workers;
-        for (int w = 0; w < nthreads; w++)
-            workers.emplace_back([&]() {
-                for (int k; (k = next.fetch_add(1)) < np;) { stage_piece(pieces[(size_t)k]); done[(size_t)k].store(1, std::memory_order_release); }
-            });
+        auto work = [&]() {
+            for (int k; (k = next.fetch_add(1)) < np;) { stage_piece(pieces[(size_t)k]); done[(size_t)k].store(1, std::memory_order_release); }
+        };
+        for (int w = 0; w < nthreads; w++) {
+            try { workers.emplace_back(work); } catch (...) { break; } // no thread to be had: the calling thread stages what is left
+        }
+        if (workers.empty()) work();
         hipError_t err = hipSuccess;
         for (int k = 0; k < np; k++) {
             while (!done[(size_t)k].load(std::memory_order_acquire)) std::this_thread::yield();
