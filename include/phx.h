@@ -45,6 +45,8 @@ extern "C" {
 #define PHX_S_TOOSHORT (-3)  /* L < 6 [UnboundLocalError/KeyError in GCframe.get, gc_frame_plot.py:53-69] */
 #define PHX_S_PARALLEL (-6)  /* a bridge edge duplicates a connect edge [ValueError, graphs.py:74] */
 #define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit) */
+#define PHX_S_LONGORF (-8)   /* an ORF of more than 65535 codons (196 kb without an in-frame stop, e.g. a scaffold's N run): the per-ORF
+                              * GC-frame class counters are 16 bit.  [the reference has no such limit] */
 #define PHX_S_NEGCYCLE (-9)  /* relaxation did not converge in V rounds */
 #define PHX_S_NOPATH 1       /* warning: target unreachable from source; 0 genes reported */
 
@@ -122,6 +124,8 @@ typedef struct phx_globals {
     int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig */
     int32_t sssp_handed_back; /* != 0: the wavefront kernel passed the contig on: 1 a node's 500 bp neighbourhood exceeds a window,
                                * 2 spill list full, 3 no convergence, 4 too many step-backs */
+    int32_t tie; /* equal-length alternatives to the shortest path (the reference's relaxation order decides, see phx_inorder.inc):
+                  * 0 none, 1 they exist and the solver's path already was the reference's, 2 the path was replaced by the reference's */
 } phx_globals;
 
 /* ---- library ---- */
@@ -134,9 +138,15 @@ const char *phx_last_error(const phx_ctx *ctx);
 /* Fills *p with the reference defaults: atg:0.85,gtg:0.10,ttg:0.05 / tag,tga,taa / minlen 90. */
 void phx_default_params(phx_params *p);
 
-/* device: HIP ordinal.  stream: a hipStream_t the caller owns (e.g. torch's current stream), or
- * NULL to let the ctx create its own.  All kernels and copies of this ctx are issued on it. */
+/* device: HIP ordinal.  stream: a hipStream_t the caller owns, or NULL to let the ctx create its own (non-blocking: it
+ * does NOT synchronise with HIP's null stream).  All kernels and copies of this ctx are issued on it. */
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out);
+/* The same with flags.  PHX_CREATE_USE_STREAM: `stream` is used exactly as given, and a NULL handle then means HIP's null
+ * (legacy default) stream — which is what torch.cuda.current_stream().cuda_stream is unless the caller switched streams —
+ * so that work of this ctx is ordered after whatever the caller enqueued there before (e.g. the kernels that produce a
+ * buffer handed to phx_attach).  On the null stream the run is enqueued kernel by kernel (HIP cannot capture it into a graph). */
+#define PHX_CREATE_USE_STREAM 1u
+int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 
 /* ---- the whole path, batched (replaces phanotate.py:40-76 for n contigs) ---- */
@@ -167,6 +177,9 @@ int phx_tap_nodes(phx_ctx *ctx, int32_t contig, phx_node *out /* [n_node], devic
 int phx_tap_edges(phx_ctx *ctx, int32_t contig, phx_edge *out /* [n_edge] */);
 /* path as device node ids, source first; dist_limbs receives n_limbs 64-bit words (two's complement) */
 int phx_tap_path(phx_ctx *ctx, int32_t contig, int32_t *path, int32_t cap, int32_t *n_path, uint64_t *dist_limbs, int32_t cap_limbs);
+/* exact distance of every node from the source: n_node x n_limbs 64-bit words (two's complement, device node order);
+ * an unreached node has a top word >= 2^61 */
+int phx_tap_dist(phx_ctx *ctx, int32_t contig, uint64_t *dist_limbs, int64_t cap_words);
 
 /* ---- the solver alone (the fastpathz boundary, phanotate.py:56-64) ----
  * Edges (src[i] -> dst[i]) over nodes 0..V-1 with integer weights given as n_limbs little-endian
@@ -177,7 +190,7 @@ int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int3
               uint64_t *dist_limbs);
 
 /* ---- measurement ---- */
-#define PHX_N_STAGES 12
+#define PHX_N_STAGES 13
 /* When on, every kernel launch of phx_run is bracketed by hipEvents on the ctx stream. */
 int phx_set_profiling(phx_ctx *ctx, int on);
 /* The same for a subset of the stages (bit k = stage k; 0 switches profiling off): two events per run instead of two per stage. */

@@ -7,7 +7,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libphx.so")
 MAXC = 16
-N_STAGES = 12
+N_STAGES = 13
 
 
 class Params(C.Structure):
@@ -36,7 +36,7 @@ class Globals(C.Structure):
         ("pos_max", C.c_double * 4), ("pos_min", C.c_double * 4),
         ("n_orf", C.c_int32), ("n_group", C.c_int32), ("n_node", C.c_int32), ("n_edge", C.c_int32), ("n_bridge", C.c_int32),
         ("n_limbs", C.c_int32), ("sssp_sweeps", C.c_int32), ("sssp_iters", C.c_int32), ("status", C.c_int32),
-        ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32),
+        ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32), ("tie", C.c_int32),
     ]
 
 
@@ -100,6 +100,7 @@ def lib():
         "phx_last_error": (C.c_char_p, [vp]),
         "phx_default_params": (None, [P(Params)]),
         "phx_create": (C.c_int, [P(Params), C.c_int, vp, P(vp)]),
+        "phx_create_ex": (C.c_int, [P(Params), C.c_int, vp, C.c_uint32, P(vp)]),
         "phx_destroy": (None, [vp]),
         "phx_annotate": (C.c_int, [vp, i32, P(C.c_char_p), P(i64), P(Result)]),
         "phx_free_results": (None, [P(Result), i32]),
@@ -114,6 +115,7 @@ def lib():
         "phx_tap_nodes": (C.c_int, [vp, i32, vp]),
         "phx_tap_edges": (C.c_int, [vp, i32, vp]),
         "phx_tap_path": (C.c_int, [vp, i32, vp, i32, P(i32), vp, i32]),
+        "phx_tap_dist": (C.c_int, [vp, i32, vp, i64]),
         "phx_solve": (C.c_int, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, i32, P(i32), vp]),
         "phx_set_profiling": (C.c_int, [vp, C.c_int]),
         "phx_set_profiling_stages": (C.c_int, [vp, C.c_uint32]),
@@ -132,7 +134,7 @@ def lib():
     return L
 
 
-EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_destroy",
+EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_create_ex", "phx_destroy",
            "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_run", "phx_download", "phx_download_flat", "phx_tap_globals",
-           "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
+           "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
            "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table"]

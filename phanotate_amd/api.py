@@ -16,10 +16,19 @@ def make_params(start_codons="atg:0.85,gtg:0.10,ttg:0.05", stop_codons="tag,tga,
     """Same flag syntax and normalisation as file_handling.get_args (file_handling.py:51-66)."""
     p = _lib.Params()
     p.minlen = int(minlen)
-    pairs = [tuple(x.split(":")) for x in start_codons.split(",")]
+    def codon_ok(c):
+        if len(c) != 3 or any(x not in "acgt" for x in c):
+            raise ValueError("codon %r: libphx takes codons of exactly 3 letters out of acgt" % c)
+        return c
+
+    pairs = []
+    for x in start_codons.split(","):
+        if x.count(":") != 1:
+            raise ValueError("start codon %r: expected codon:weight" % x)
+        pairs.append(tuple(x.split(":")))
     seen = {}
     for codon, w in pairs:  # dict semantics: a repeated codon keeps its first position, last weight
-        seen[codon.lower()] = float(w)
+        seen[codon_ok(codon.lower())] = float(w)
     m = max(seen.values())
     if len(seen) > _lib.MAXC:
         raise ValueError("at most %d start codons" % _lib.MAXC)
@@ -27,7 +36,7 @@ def make_params(start_codons="atg:0.85,gtg:0.10,ttg:0.05", stop_codons="tag,tga,
     for i, (codon, w) in enumerate(seen.items()):
         p.start[i].value = codon.encode()
         p.start_w[i] = w / m
-    stops = [c.lower() for c in stop_codons.split(",")]
+    stops = [codon_ok(c.lower()) for c in stop_codons.split(",")]
     if len(stops) > _lib.MAXC:
         raise ValueError("at most %d stop codons" % _lib.MAXC)
     p.n_stop = len(stops)
@@ -46,13 +55,20 @@ def synth_contig(seed, L=50000):
 
 
 class Annotator:
-    """One libphx context = one (host thread, GPU).  `stream` is a raw hipStream_t (int) or None."""
+    """One libphx context = one (host thread, GPU).
+
+    `stream`: None lets the context create its own (non-blocking) stream; an int is a raw hipStream_t used as given —
+    0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
+    context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
     def __init__(self, params=None, device=0, stream=None):
         self.L = _lib.lib()
         self.params = params or make_params()
         h = C.c_void_p()
-        rc = self.L.phx_create(C.byref(self.params), int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if stream is None:
+            rc = self.L.phx_create_ex(C.byref(self.params), int(device), None, 0, C.byref(h))
+        else:
+            rc = self.L.phx_create_ex(C.byref(self.params), int(device), C.c_void_p(int(stream)), 1, C.byref(h))
         if rc:
             raise PhxError(rc, "%s (%s)" % (self.L.phx_strerror(rc).decode(), self.L.phx_last_error(None).decode()))
         self.h = h
@@ -156,6 +172,22 @@ class Annotator:
         if v >> (64 * nl - 1):
             v -= 1 << (64 * nl)
         return p[: n.value].copy(), v
+
+    def dist(self, i):
+        """Exact distance of every node from the source as python ints (None: unreached), device node order."""
+        g = self.globals(i)
+        nl, V = max(g.n_limbs, 1), max(g.n_node, 0)
+        a = np.zeros((max(V, 1), nl), np.uint64)
+        self._chk(self.L.phx_tap_dist(self.h, i, a.ctypes.data_as(C.c_void_p), a.size), "phx_tap_dist")
+        out = []
+        for v in range(V):
+            x = 0
+            for k in range(nl):
+                x |= int(a[v, k]) << (64 * k)
+            if x >> (64 * nl - 1):
+                x -= 1 << (64 * nl)
+            out.append(None if x >= 1 << (64 * nl - 3) else x)
+        return out
 
     # ---- solver alone (fastpathz boundary) ----
     def solve(self, V, src, dst, weights, source, target, n_limbs=None):

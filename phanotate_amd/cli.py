@@ -17,7 +17,7 @@ from .shard import run_sharded
 from .writers import FORMATS, write
 
 STATUS_TEXT = {-2: "letter outside the nucleotide alphabet (the reference raises KeyError)", -3: "contig shorter than 6 bases",
-               -6: "parallel edges are forbidden (graphs.py:74)", -7: "integer overflow in path sums", -9: "negative cycle"}
+               -6: "parallel edges are forbidden (graphs.py:74)", -7: "integer overflow in path sums", -8: "an open reading frame of more than 65535 codons", -9: "negative cycle"}
 
 
 def is_valid_file(x):

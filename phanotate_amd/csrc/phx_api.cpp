@@ -21,8 +21,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_EDGE_WEIGHTS, ST_COPY };
-const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "edge_weights", "copies"};
+enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_EDGE_WEIGHTS, ST_COPY, ST_INORDER };
+const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "edge_weights", "copies", "inorder"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -81,6 +81,9 @@ struct phx_ctx {
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
+    DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
+    int64_t tie_seen = 0; // largest DTotals.tie_need a run reported
+    DevBuf b_ekey;        // phx_solve: rank of every edge in the caller's order
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
@@ -176,10 +179,13 @@ int check_params(const phx_params *p) {
     if (!p || p->minlen < 6 || p->n_start < 1 || p->n_start > PHX_MAX_CODONS || p->n_stop < 1 || p->n_stop > PHX_MAX_CODONS) return PHX_E_PARAM;
     for (int i = 0; i < p->n_start; i++) {
         for (int j = 0; j < 3; j++) if (code_of(p->start[i][j]) < 0) return PHX_E_PARAM;
+        if (p->start[i][3] != 0) return PHX_E_PARAM;
         if (!(p->start_w[i] == p->start_w[i])) return PHX_E_PARAM;
     }
-    for (int i = 0; i < p->n_stop; i++)
+    for (int i = 0; i < p->n_stop; i++) {
         for (int j = 0; j < 3; j++) if (code_of(p->stop[i][j]) < 0) return PHX_E_PARAM;
+        if (p->stop[i][3] != 0) return PHX_E_PARAM;
+    }
     return PHX_OK;
 }
 
@@ -246,7 +252,7 @@ int64_t cap_of(const DevBuf &b, size_t elem, int64_t reserve) {
 void current_caps(const phx_ctx *c, DCaps *k) {
     const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
     k->orf = cap_of(c->b_orf, sizeof(DOrf), 1);
-    k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, sizeof(DGene), 1));
+    k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, 2 * sizeof(DGene), 1)); // a path k_inorder replaces may take new gene slots
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
     for (const DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist}) v = std::min(v, cap_of(*q, 4, 8));
     v = std::min(v, cap_of(c->b_no, 8, 8));
@@ -284,15 +290,16 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
-    b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr;
+    b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
+    b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
     b->gene_total = (uint32_t *)c->b_gtot.p;
 }
 
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
+    c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     if (n < 0) return PHX_E_ARG;
-    c->n = n;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
     c->graph_valid = false; c->tiles_dirty = true; c->meta0_dirty = true; c->runs_on_layout = 0;
@@ -302,7 +309,6 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
         DMeta &m = c->meta[(size_t)i];
-        memset(&m, 0, sizeof(m));
         c->max_len = std::max<int64_t>(c->max_len, L);
         m.off = offsets_or_null ? offsets_or_null[i] : off;
         m.L = (int32_t)L;
@@ -319,8 +325,7 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     }
     c->tot_words = words; c->tot_items = items; c->tot_nbits = nbw; c->tot_bridge = nbr;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
-    c->uploaded = true;
-    c->ran = false;
+    c->n = n; // the callers set `uploaded` once the bases are where the kernels read them
     return PHX_OK;
 }
 
@@ -365,6 +370,7 @@ const char *phx_strerror(int code) {
     case PHX_S_TOOSHORT: return "contig shorter than 6 bases";
     case PHX_S_PARALLEL: return "bridge edge duplicates a connect edge";
     case PHX_S_OVERFLOW: return "integer path sums overflow";
+    case PHX_S_LONGORF: return "an open reading frame of more than 65535 codons";
     case PHX_S_NEGCYCLE: return "relaxation did not converge";
     case PHX_S_NOPATH: return "target unreachable";
     default: return "unknown";
@@ -392,8 +398,10 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
     return PHX_OK;
 }
 
-int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) {
-    if (!out) return PHX_E_ARG;
+int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
+
+int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
+    if (!out || (flags & ~PHX_CREATE_USE_STREAM) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -410,8 +418,10 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
     c->graphs_enabled = getenv("PHX_NO_GRAPH") == nullptr;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else {
+    if (flags & PHX_CREATE_USE_STREAM) { // as given; a null handle is HIP's null stream
+        c->stream = (hipStream_t)stream; c->own_stream = false;
+        if (!stream) c->graphs_enabled = false; // the legacy stream cannot be captured
+    } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         c->own_stream = true;
     }
@@ -450,7 +460,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -535,6 +545,7 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         HIPCHK(c, err);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
     return PHX_OK;
 }
 
@@ -544,6 +555,7 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
     int rc = set_batch_layout(c, n, nullptr, offsets);
     if (rc) return rc;
     c->attached = d_ascii;
+    c->uploaded = true;
     return PHX_OK;
 }
 
@@ -587,7 +599,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_cbits, (size_t)(ht->cb + 8) * 8))) return rc;
         if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
-        if ((rc = ensure(c, c->b_genes, sizeof(DGene) * G))) return rc;
+        if ((rc = ensure(c, c->b_genes, 2 * sizeof(DGene) * G))) return rc;
         if ((rc = ensure(c, c->b_node, NV * sizeof(DNode)))) return rc;
         for (DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist})
             if ((rc = ensure(c, *q, NV * 4))) return rc;
@@ -678,6 +690,12 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
         if (early) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
     }
+    {
+        StageTimer t(c, ST_INORDER);
+        int nlm = 0;
+        for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
+        phxk_inorder(&b, nlm, s);
+    } // equal-length alternatives: the parents of the reference's relaxation order
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
@@ -706,6 +724,7 @@ int run_once(phx_ctx *c, bool learn) {
     if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
     if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
     if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tie, (size_t)std::max<int64_t>(1 << 20, c->tie_seen + c->tie_seen / 4)))) return rc;
     if (c->meta0_dirty) { // once per batch layout: the records a run starts from (offsets and lengths set, accumulators zero)
         for (DMeta &m : c->meta) {
             DMeta k = m;
@@ -759,6 +778,7 @@ int run_once(phx_ctx *c, bool learn) {
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
     const DTotals *ht = c->h_tot;
+    c->tie_seen = std::max(c->tie_seen, ht->tie_need);
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = (ht->class_mask & ~mask) == 0;
     for (int k = 0; k < 4; k++) covered = covered && ht->lds_need[k] <= lds[k];
@@ -931,6 +951,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->sssp_iters = m.sssp_iters;
     out->sssp_kernel = m.sssp_mode;
     out->sssp_handed_back = m.sssp_why > 0 ? m.sssp_why : 0;
+    out->tie = m.tie;
     return PHX_OK;
 }
 
@@ -1074,6 +1095,15 @@ int phx_tap_path(phx_ctx *c, int32_t contig, int32_t *path, int32_t cap, int32_t
     return PHX_OK;
 }
 
+int phx_tap_dist(phx_ctx *c, int32_t contig, uint64_t *dist_limbs, int64_t cap_words) {
+    TAP_PRE(c, contig);
+    if (m.status < 0 || m.n_node <= 2) return PHX_OK;
+    const size_t words = (size_t)m.n_node * (size_t)m.sssp_nl;
+    if (!dist_limbs || cap_words < (int64_t)words) return PHX_E_ARG;
+    HIPCHK(c, hipMemcpy(dist_limbs, (uint64_t *)c->b_dist.p + (size_t)m.node_off * (size_t)c->n_limbs, words * 8, hipMemcpyDeviceToHost));
+    return PHX_OK;
+}
+
 // ---- the solver alone ----
 int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs, int32_t n_limbs,
               int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path, uint64_t *dist_limbs) {
@@ -1105,6 +1135,11 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
             memcpy(&ewl[(size_t)k * (size_t)n_limbs], &w_limbs[(size_t)e * (size_t)n_limbs], (size_t)n_limbs * 8);
         }
     }
+    std::vector<uint32_t> ekey((size_t)E);
+    {
+        std::vector<uint32_t> fill(in_off.begin(), in_off.end() - 1);
+        for (int e = 0; e < E; e++) ekey[fill[(size_t)to_dev[(size_t)dst[e]]]++] = (uint32_t)e; // same stable placement as above: the caller's index of every device edge
+    }
     DMeta m;
     memset(&m, 0, sizeof(m));
     m.n_node = V; m.n_edge = E; m.L = 1; m.sssp_nl = n_limbs; m.sssp_mode = 0;
@@ -1113,10 +1148,13 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     if ((rc = ensure(c, b_meta, sizeof(DMeta) * 2))) return rc;
     if ((rc = ensure(c, c->b_inoff, ((size_t)V + 2) * 4))) return rc;
     if ((rc = ensure(c, c->b_esrc, ((size_t)E + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_ekey, ((size_t)E + 1) * 4))) return rc;
     if ((rc = ensure(c, c->b_ew, ((size_t)E + 1) * 8))) return rc;
     if ((rc = ensure(c, c->b_ewl, ((size_t)E + 1) * 8 * (size_t)n_limbs))) return rc;
     if ((rc = ensure(c, c->b_dist, ((size_t)V + 1) * 8 * (size_t)n_limbs))) return rc;
     if ((rc = ensure(c, c->b_parent, ((size_t)V + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_path, ((size_t)V + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_tie, (size_t)V * 40 + (size_t)E * 12 + 64))) return rc; // k_inorder's worst case for one graph
     if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
     c->uploaded = false; c->ran = false; // the batch buffers are being reused
     hipStream_t s = c->stream;
@@ -1125,6 +1163,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     HIPCHK(c, hipMemcpyAsync(c->b_inoff.p, in_off.data(), ((size_t)V + 1) * 4, hipMemcpyHostToDevice, s));
     if (E) {
         HIPCHK(c, hipMemcpyAsync(c->b_esrc.p, esrc.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->b_ekey.p, ekey.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->b_ewl.p, ewl.data(), (size_t)E * 8 * (size_t)n_limbs, hipMemcpyHostToDevice, s));
     }
     DBatch b;
@@ -1134,26 +1173,26 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     b.tot = (DTotals *)c->b_tot.p;
     b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (double *)c->b_ew.p;
     b.ewl = (const uint64_t *)c->b_ewl.p;
+    b.ekey = (const uint32_t *)c->b_ekey.p;
     b.dist = (uint64_t *)c->b_dist.p; b.parent = (int32_t *)c->b_parent.p;
+    b.path = (int32_t *)c->b_path.p; // no b.genes: the kernels stop at the path
+    b.tie = (uint8_t *)c->b_tie.p; b.tie_cap = cap_of(c->b_tie, 1, 0);
     b.dist_stride = n_limbs;
+    // relaxation (k_sssp), walk (k_path), parents of the caller's relaxation order where equal-length paths exist (k_inorder)
     hipLaunchSsspOnly(&b, n_limbs, s);
     HIPCHK(c, hipGetLastError());
-    std::vector<int32_t> parent((size_t)V);
-    std::vector<uint64_t> dist((size_t)V * (size_t)n_limbs);
-    HIPCHK(c, hipMemcpyAsync(parent.data(), c->b_parent.p, (size_t)V * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(dist.data(), c->b_dist.p, (size_t)V * 8 * (size_t)n_limbs, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> path((size_t)V);
+    std::vector<uint64_t> dt((size_t)n_limbs);
     HIPCHK(c, hipMemcpyAsync(&m, b_meta.p, sizeof(m), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(path.data(), c->b_path.p, (size_t)V * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(dt.data(), (uint64_t *)c->b_dist.p + (size_t)(V - 1) * (size_t)n_limbs, (size_t)n_limbs * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (m.status < 0) return m.status;
-    const uint64_t *dt = &dist[(size_t)(V - 1) * (size_t)n_limbs];
-    if (dt[n_limbs - 1] == 0x7fffffffffffffffull) return PHX_OK; // unreachable: *n_path = 0
-    std::vector<int32_t> rev;
-    for (int v = V - 1; v != V - 2 && (int)rev.size() <= V; v = (int)esrc[(size_t)(uint32_t)parent[(size_t)v]]) rev.push_back(v); // parent holds in-edge indices
-    rev.push_back(V - 2);
-    if ((int)rev.size() > cap && path_out) return PHX_E_ARG;
-    *n_path = (int32_t)rev.size();
-    if (path_out) for (size_t k = 0; k < rev.size(); k++) path_out[k] = to_user[(size_t)rev[rev.size() - 1 - k]];
-    if (dist_limbs) memcpy(dist_limbs, dt, (size_t)n_limbs * 8);
+    if (m.n_path < 2) return PHX_OK; // unreachable: *n_path = 0
+    if (m.n_path > cap && path_out) return PHX_E_ARG;
+    *n_path = m.n_path;
+    if (path_out) for (int k = 0; k < m.n_path; k++) path_out[k] = to_user[(size_t)path[(size_t)k]];
+    if (dist_limbs) memcpy(dist_limbs, dt.data(), (size_t)n_limbs * 8);
     return PHX_OK;
 }
 

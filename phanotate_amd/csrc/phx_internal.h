@@ -115,6 +115,9 @@ struct DMeta { // one per contig
     int32_t dense;     // some node has more than ~62 close / open nodes within the next 500 bp: k_sssp_wave's windows cannot take it (k_edges<false>)
     double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
     int64_t win_off;   // first window record of this contig in DBatch.win (capacity n_node/16 + 7)
+    int32_t tie;       // k_inorder: 0 the shortest path is unique, 1 equal-length alternatives exist and the solver's path is the in-order one,
+                       // 2 the path was replaced by the in-order one, -1 not resolved (cannot happen)
+    int32_t pad0;
 };
 
 struct DTile {
@@ -154,8 +157,10 @@ struct DTotals {
     int32_t class_mask;  // bit 4*k + mode: some contig wants limb class k (2,4,8,17 limbs) solved by kernel `mode`;
                          // bit 16 + k: class k has contigs that were routed to the workgroup kernel from the start (dense)
     int32_t vmax;        // largest node count
-    int32_t overflow;    // bit 0: ORF/node buffers, bit 1: edge/distance buffers too small -> the later kernels do nothing
+    int32_t overflow;    // bit 0: ORF/node buffers, bit 1: edge/distance buffers too small -> the later kernels do nothing;
+                         // bit 2: k_inorder's scratch (DBatch.tie) too small: tie_need bytes are wanted
     int64_t lds_need[4]; // per limb class: dynamic LDS k_sssp_lds needs (max over the contigs it may get)
+    int64_t tie_need;    // bytes of scratch the contigs with equal-length alternative paths asked for (k_inorder)
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
@@ -199,6 +204,9 @@ struct DBatch {
     uint32_t *esrc;
     double *ew;
     const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge
+    const uint32_t *ekey; // optional rank of every edge in the caller's edge order (phx_solve); else the reference's node insertion order is used
+    uint8_t *tie;        // scratch of k_inorder (bump-allocated through DTotals.tie_need)
+    int64_t tie_cap;
     int32_t defer_overlap; // 1: k_edges<true> records overlap edges, k_edge_weights evaluates them (needs node ids < 2^21)
     // output
     int32_t *path;
@@ -227,6 +235,7 @@ size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
+void phxk_inorder(const DBatch *b, int nl_mask, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@
 //                  / contig)
 //                  k_sssp_lds<NL> (workgroup / contig),     phx_sssp.inc       integers; path -> genes phanotate.py:65-76,
 //                  k_sssp<NL> + k_path<NL> (global memory)                     locus.py:29-37
+//                  k_inorder (ties between equal-length paths)  phx_inorder.inc    relaxation order of the reference's solver
 //
 // No MFMA anywhere: the path has no dense contraction.  All integer outputs are
 // bit-exact with the reference; fp64 is used where the reference uses Decimal (edge weights only).
@@ -118,6 +119,7 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 #include "phx_sssp.inc"
 #include "phx_layout.inc"
 #include "phx_sssp_wave.inc"
+#include "phx_inorder.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -150,16 +152,20 @@ void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream) {
     if (b->defer_overlap && n_edges > 0)
         hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + EW_T * EW_PER - 1) / (EW_T * EW_PER))), dim3(EW_T), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
 }
-// phx_solve: the relaxation alone, no path/gene emission (the caller walks the parent edges)
+// phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
-    dim3 g(b->n_contig), t(NT);
+    phxk_sssp(b, nl, 0, 0, stream);
+    phxk_inorder(b, nl == 2 ? 1 : nl == 4 ? 2 : nl == 8 ? 4 : 8, stream);
+}
+
+// nl_mask: bit k set = some contig of the batch has 2 / 4 / 8 / 17 limbs (k = 0..3)
+void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
+    dim3 g(b->n_contig), t(IO_T);
     hipStream_t s = (hipStream_t)stream;
-    switch (nl) {
-    case 2: hipLaunchKernelGGL(k_sssp<2>, g, t, 0, s, *b); break;
-    case 4: hipLaunchKernelGGL(k_sssp<4>, g, t, 0, s, *b); break;
-    case 8: hipLaunchKernelGGL(k_sssp<8>, g, t, 0, s, *b); break;
-    default: hipLaunchKernelGGL(k_sssp<17>, g, t, 0, s, *b); break;
-    }
+    if (nl_mask & 1) hipLaunchKernelGGL(k_inorder<2>, g, t, 0, s, *b);
+    if (nl_mask & 2) hipLaunchKernelGGL(k_inorder<4>, g, t, 0, s, *b);
+    if (nl_mask & 4) hipLaunchKernelGGL(k_inorder<8>, g, t, 0, s, *b);
+    if (nl_mask & 8) hipLaunchKernelGGL(k_inorder<17>, g, t, 0, s, *b);
 }
 
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }

@@ -42,3 +42,51 @@ def oracle():
 
     orc.build()
     return orc
+
+
+# ---- the solver boundary, restated for the tests (the golden generator's rule, tests/golden/make_golden.py:100-133) ----
+def inorder_bellman_ford(V, edges, s):
+    """In-place Bellman-Ford over `edges` = [(u, v, w int)] in the given order with a strict '<' (what the reference feeds
+    fastpathz: Graph.iteredges order, phanotate.py:56-64).  Returns (dist, parent edge index per node) or (None, None)
+    when it does not settle in V rounds."""
+    dist = [None] * V
+    par = [-1] * V
+    dist[s] = 0
+    for _ in range(V + 1):
+        ch = False
+        for i, (u, v, w) in enumerate(edges):
+            du = dist[u]
+            if du is None:
+                continue
+            nd = du + w
+            if dist[v] is None or nd < dist[v]:
+                dist[v] = nd
+                par[v] = i
+                ch = True
+        if not ch:
+            return dist, par
+    return None, None
+
+
+def exact_dist_from_device_edges(ann, i):
+    """Exact distances (python ints) over the graph libphx built for contig i, from ITS OWN fp64 weights
+    (phx_tap_edges): weight = trunc(w*1000), edges.py:22.  The device's 128..1088-bit sums must equal these bit for bit."""
+    import math
+
+    ed = ann.edges(i)
+    V = int(ann.globals(i).n_node)
+    src = ed["src"].tolist()
+    dst = ed["dst"].tolist()
+    w = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
+    dist = [None] * V
+    dist[V - 2] = 0
+    for _ in range(V + 1):  # edges are grouped by destination in position order: a handful of sweeps
+        ch = False
+        for k in range(len(src)):
+            du = dist[src[k]]
+            if du is not None and (dist[dst[k]] is None or du + w[k] < dist[dst[k]]):
+                dist[dst[k]] = du + w[k]
+                ch = True
+        if not ch:
+            break
+    return dist

@@ -49,9 +49,19 @@ def test_no_cpu_fallback():
 def test_bad_params_rejected():
     lib = _lib.lib()
     h = C.c_void_p()
-    for bad in (pa.make_params(minlen=3), pa.make_params(start_codons="anx:1"), pa.make_params(stop_codons="ta")):
-        rc = lib.phx_create(C.byref(bad), 0, None, C.byref(h))
-        assert rc == -14, rc
+    bads = [pa.make_params(minlen=3)]
+    for field, text in (("start", b"anx"), ("stop", b"ta"), ("start", b"atgc")):  # a bad letter, a short codon, a 4-letter codon without NUL
+        q = pa.make_params()
+        C.memmove(C.addressof(getattr(q, field)[0]), text + b"\0" * (4 - len(text)), 4)
+        bads.append(q)
+    for bad in bads:
+        assert lib.phx_create(C.byref(bad), 0, None, C.byref(h)) == -14
+        assert lib.phx_create_ex(C.byref(bad), 0, None, 1, C.byref(h)) == -14
+    assert lib.phx_create_ex(C.byref(pa.make_params()), 0, None, 2, C.byref(h)) == -1  # unknown flag
+    # the binding refuses them before they reach the library (the reference would keep such codons as keys that never match)
+    for kw in (dict(start_codons="anx:1"), dict(stop_codons="ta"), dict(start_codons="atgc:1"), dict(start_codons="atg")):
+        with pytest.raises(ValueError):
+            pa.make_params(**kw)
 
 
 def test_default_params_match_reference_flags():
