@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — Mbp/s annotated on synthetic 50 kb phage contigs (BASELINE.json metric).
 
-A "step" is one pass of the whole hot path (libphx phx_run: features -> ORF scan -> scoring ->
-graph -> exact shortest path -> genes) over one batch of synthetic contigs that is already
-resident in HBM.  Weak scaling: every rank (= one GPU) owns its own batch of --contigs contigs
-(seeds disjoint per rank); there is no data-path collective — contigs are independent
-(phanotate.py:40,56) — only the barrier / max-over-ranks around the timed region.
+A "step" is one pass of the whole hot path (libphx phx_run: features -> ORF scan -> scoring -> graph -> exact shortest
+path -> genes) over one batch of contigs that is already resident in HBM: that is `value` (task contract).  The metric
+SURVEY.md §8(d) defines — host ASCII contigs -> host gene lists, i.e. H2D + every kernel + D2H (+ the gather to rank 0
+when N > 1) — is timed the same way (K steps, barrier + synchronize on both sides, max over ranks) and reported beside it as
+`host_to_host`.
+
+Workloads (BASELINE.json configs):
+  N = 1 (default)         config 4: 1000 synthetic 50 kb contigs (seeds 0..999) on one GPU
+  N > 1                   config 5: 10 000 synthetic 50 kb contigs (seeds 0..9999) sharded per contig over the N ranks by
+                          phanotate_amd.shard.partition (1250 per GPU at N = 8); no collective in the data path, rank 0
+                          gathers the gene lists (shard.run_sharded_flat)
+  --workload lambda | t4  configs 2-3: one contig (tests/golden/NC_001416.1 48.5 kb / NC_000866.1 169 kb) on one GPU
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
+import gzip
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,6 +33,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SINGLE = {"lambda": "NC_001416.1", "t4": "NC_000866.1"}
 
 
 def algorithmic_bytes(sz):
@@ -31,13 +44,13 @@ def algorithmic_bytes(sz):
 
 STAGE_KERNEL = {"sssp": "k_sssp_wave<2>", "features": "k_features", "edges_fill": "k_edges<true>", "edges_count": "k_edges<false>",
                 "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true>", "orf_count": "k_orf<false>", "nodes": "k_node_build", "score": "k_score",
-                "edge_weights": "k_edge_weights"}
+                "edge_weights": "k_edge_weights", "inorder": "k_inorder<2>"}
 
 
 def pmc_traffic(stage, contigs, length):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC run (profiles/traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by tools/pmc_summary.py).
-    Only meaningful for the workload it was collected on."""
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC run (profiles/traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes of `bench.py`, gfx950 correction applied by tools/pmc_summary.py).  It is NOT measured in
+    this process (counters need rocprofv3); only meaningful for the workload it was collected on."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if contigs != 1000 or length != 50000 or stage not in STAGE_KERNEL or not os.path.exists(path):
         return None
@@ -51,20 +64,112 @@ def pmc_traffic(stage, contigs, length):
     return None
 
 
+def read_golden_fasta(case):
+    with gzip.open(os.path.join(GOLDEN, case + ".fasta.gz"), "rt") as f:
+        lines = f.read().split("\n")
+    return "".join(lines[1:]).encode()
+
+
+def reference_python_rate():
+    """The reference's own Python (get_orfs + get_graph), timed in the build container when the golden vectors were made
+    (tests/golden/make_golden.py stores the seconds in every fixture): kbp/s per core on the synthetic 50 kb fixtures.
+    Cross-machine: never a ratio against this box."""
+    import numpy as np
+
+    rates = []
+    for fn in sorted(glob.glob(os.path.join(GOLDEN, "synth50k_*.npz"))):
+        g = np.load(fn)
+        if "ref_seconds" in g:
+            rates.append(float(g["L"]) / float(np.sum(g["ref_seconds"])) / 1e3)
+    if not rates:
+        return None
+    return {"kbp_s_per_core": round(sum(rates) / len(rates), 3), "min": round(min(rates), 3), "max": round(max(rates), 3), "contigs": len(rates),
+            "what": "phanotate_modules.functions get_orfs + get_graph (no solver, no I/O), 1 core, build container (Xeon 2.1 GHz), from tests/golden/synth50k_*.npz"}
+
+
+def cpu_baselines(seqs, L_, n_one, per_core):
+    """The C oracle (oracle/phx_oracle.c: orc_run, all three stages) on a bounded sample of the same batch: one thread, then one
+    thread per host core (one contig per thread at a time; orc_run keeps no global state and ctypes releases the GIL)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+
+    lib, P = oracle.lib(), oracle.make_params()
+
+    def one_contig(seq):
+        r = oracle.Result()
+        lib.orc_run(seq, len(seq), C.byref(P), 3, C.byref(r))
+        st = r.status
+        lib.orc_free(C.byref(r))
+        return st
+
+    n1 = max(1, min(n_one, len(seqs)))
+    t0 = time.perf_counter()
+    for i in range(n1):
+        assert one_contig(seqs[i]) == 0
+    t1 = time.perf_counter() - t0
+    one = {"value": round(n1 * L_ / t1 / 1e6, 4), "unit": "Mbp/s", "cores": 1, "kind": "port",
+           "sample": "first %d of the %d contigs of this batch, C oracle (oracle/phx_oracle.c), %.1f s" % (n1, len(seqs), t1)}
+    cores = os.cpu_count() or 1
+    nall = max(1, min(len(seqs), per_core * cores))
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(one_contig, seqs[:cores]))  # start the threads
+        t0 = time.perf_counter()
+        st = list(ex.map(one_contig, seqs[:nall]))
+        ta = time.perf_counter() - t0
+    assert all(x == 0 for x in st)
+    allc = {"value": round(nall * L_ / ta / 1e6, 4), "unit": "Mbp/s", "cores": cores, "kind": "port",
+            "sample": "first %d contigs, one contig per thread on %d host cores (os.cpu_count), %.1f s" % (nall, cores, ta)}
+    return one, allc
+
+
+def cli_end_to_end(seqs, device):
+    """phanotate.py (the drop-in CLI) on a FASTA of these contigs: seconds for parsing, the GPU path and formatting."""
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "in.fasta")
+        with open(fa, "wb") as f:
+            for i, s in enumerate(seqs):
+                f.write(b">contig%05d synthetic\n" % i)
+                for k in range(0, len(s), 70):
+                    f.write(s[k : k + 70] + b"\n")
+        out = os.path.join(td, "out.tsv")
+        env = dict(os.environ, PHX_CLI_TIMING="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), "--device", str(device), "-o", out, fa], capture_output=True, text=True, env=env, timeout=1800)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        timing = {}
+        for line in r.stderr.splitlines():
+            if line.startswith("PHX_CLI_TIMING "):
+                timing = json.loads(line[len("PHX_CLI_TIMING "):])
+        bases = sum(len(s) for s in seqs)
+        timing.update({"contigs": len(seqs), "process_wall_s": round(wall, 3), "output_bytes": os.path.getsize(out),
+                       "Mbp_s_process_wall": round(bases / wall / 1e6, 2)})
+        return timing
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--contigs", type=int, default=1000, help="contigs per GPU (BASELINE config 4: 1000 x 50 kb on 1 GPU)")
+    ap.add_argument("--workload", choices=["synthetic", "lambda", "t4"], default="synthetic")
+    ap.add_argument("--contigs", type=int, default=None, help="total synthetic contigs [1000 at N=1 (config 4), 10000 at N>1 (config 5)]")
     ap.add_argument("--length", type=int, default=50000)
-    ap.add_argument("--cpu-contigs", type=int, default=256, help="size of the bounded sample timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-contigs", type=int, default=192, help="bounded sample for the 1-core CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-per-core", type=int, default=4, help="contigs per host core in the all-core CPU baseline")
+    ap.add_argument("--cli-contigs", type=int, default=1000, help="contigs of the end-to-end phanotate.py run (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-contig lines, the CPU baselines and the CLI run")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
 
     import phanotate_amd as pa
+    from phanotate_amd.shard import partition, run_sharded_flat
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,28 +190,46 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # synthetic contigs: rank r owns seeds r*C .. r*C+C-1
-    C_, L_ = args.contigs, args.length
-    seqs = [pa.synth_contig(rank * C_ + i, L_) for i in range(C_)]
-    stream = torch.cuda.current_stream().cuda_stream
-    ann = pa.Annotator(device=local_rank, stream=stream)
-
-    # PCIe-inclusive pass (H2D of the ASCII + kernels + D2H of the gene lists): the second call, when the context's
-    # buffers exist.  Reported as `pcie_inclusive_Mbp_s` — never `value`.
-    res = ann.annotate(seqs)
-    t_e2e = 1e30
-    for _ in range(3):
-        t0 = time.perf_counter()
-        res = ann.annotate(seqs)
-        t_e2e = min(t_e2e, time.perf_counter() - t0)
-    n_genes = sum(len(g) for _, g in res)
-    n_bad = sum(1 for st, _ in res if st < 0)
+    L_ = args.length
+    if args.workload == "synthetic":
+        n_total = args.contigs if args.contigs else (1000 if world == 1 else 10000)
+        # config 5: the whole job is seeds 0..n_total-1; this rank's shard by the product's partitioner (equal lengths: the
+        # partition only needs the lengths, so every rank derives it without generating the other ranks' contigs)
+        mine = list(range(n_total)) if world == 1 else partition([L_] * n_total, world)[rank]
+        seqs = [pa.synth_contig(i, L_) for i in mine]
+        wl = ("batch of %d synthetic %d bp phage contigs on one GPU, resident in HBM (BASELINE config 4)" % (n_total, L_)) if world == 1 else (
+            "%d synthetic %d bp phage contigs (seeds 0..%d) sharded per contig over %d GPUs by shard.partition, %d on rank 0 (BASELINE config 5)" % (n_total, L_, n_total - 1, world, len(mine)))
+    else:
+        if world != 1:
+            sys.stderr.write("bench.py: a single contig is never split across GPUs (replicas only): run --workload %s with --gpus 1\n" % args.workload)
+            sys.exit(2)
+        n_total, mine = 1, [0]
+        seqs = [read_golden_fasta(SINGLE[args.workload])]
+        L_ = len(seqs[0])
+        wl = "%s, one %d bp contig on one GPU (BASELINE config %d)" % (SINGLE[args.workload], L_, 2 if args.workload == "lambda" else 3)
+    ann = pa.Annotator(device=local_rank)  # the context's own stream; torch is only here for the process group and the barrier
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        # (the context's stream is idle between calls: phx_run / phx_download block until their results are on the host)
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    status, offs, genes = ann.annotate_flat(seqs)  # sizes the context's buffers
     for _ in range(args.warmup):
         ann.run()
     # untimed pass with every stage bracketed by HIP events: the stage table, and which kernel dominates
@@ -117,31 +240,42 @@ def main():
     stages_all = ann.stage_ms(reset=True)
     kern = {k: v for k, v in stages_all.items() if k not in ("copies", "memset") and v[1] > 0}
     dom = max(kern, key=lambda k: kern[k][0])
-    # timed region: K steps; only the dominant stage keeps its two HIP events (on the launch stream), the rest of the
-    # run is enqueued without any (a full set of stage events costs 3 % of the step)
+    kernel_ms_per_step = sum(v[0] for v in kern.values()) / 3
+    # ---- timed region A (`value`): K steps on the resident batch; only the dominant stage keeps its two HIP events (on the
+    #      launch stream), the rest of the run is enqueued without any (a full set of stage events costs 3 % of the step)
     ann.set_profiling_stages([dom])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ann.run()
     barrier()
-    dt = time.perf_counter() - t0
+    dt = max_over_ranks(time.perf_counter() - t0)
     dom_total, dom_n = ann.stage_ms(reset=True)[dom]
     ann.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     sz = ann.batch_sizes()
-    bp_total = float(sz["L"]) * world  # every rank holds the same amount of bases
+    bp_total = sum_over_ranks(float(sum(len(s) for s in seqs)))
     value = bp_total * args.steps / dt / 1e6
 
+    # ---- timed region B: host ASCII -> host gene lists: upload, every kernel, download, gather to rank 0 ----
+    def host_step():
+        return run_sharded_flat(seqs, ann.annotate_flat, rank, world, dist, mine=(mine, n_total))
+
+    host_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = host_step()
+    barrier()
+    dt_host = max_over_ranks(time.perf_counter() - t0)
+
     if rank == 0:
+        st_all, offs_all, genes_all = merged
         dom_ms = dom_total / max(dom_n, 1)
         balgo = algorithmic_bytes(sz)
         achieved = balgo / (dom_ms * 1e-3) / 1e9
+        step_achieved = balgo / (kernel_ms_per_step * 1e-3) / 1e9
         out = {
-            "metric": "Mbp/s annotated (whole node) on 50 kb synthetic phage contigs",
+            "metric": "Mbp/s annotated (whole node) on 50 kb synthetic phage contigs" if args.workload == "synthetic" else "Mbp/s annotated, single contig",
             "value": round(value, 3),
             "unit": "Mbp/s",
             "n_gpus": world,
@@ -149,18 +283,27 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "u8/int128 (fp64 edge weights)",
-            "data": "synthetic",
+            "data": "synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)",
+            "value_is": "inputs resident in HBM when the timed region starts (task contract); host ASCII -> host gene lists is `host_to_host`",
             "config": {
-                "workload": "batch of %d synthetic %d bp phage contigs per GPU, resident in HBM (BASELINE config 4)" % (C_, L_),
-                "contigs_per_gpu": C_,
+                "workload": wl,
+                "contigs_total": n_total,
+                "contigs_rank0": len(seqs),
                 "contig_length": L_,
-                "sharding": "per-contig across %d GPU(s), no collective in the data path" % world,
-                "genes_called_rank0": n_genes,
-                "contigs_with_error_status": n_bad,
+                "sharding": "per-contig across %d GPU(s) (phanotate_amd.shard.partition), no collective in the data path" % world,
+                "genes_called_total": int(len(genes_all)),
+                "contigs_with_error_status": int((st_all < 0).sum()),
                 "int_limbs": int(ann.globals(0).n_limbs),
+                "solver_kernel_contig0": int(ann.globals(0).sssp_kernel),
+            },
+            "host_to_host": {
+                "value": round(bp_total * args.steps / dt_host / 1e6, 3),
+                "unit": "Mbp/s",
+                "ms_per_step": round(dt_host / args.steps * 1e3, 4),
+                "what": "SURVEY.md §8(d): host ASCII contigs -> host gene lists (phx_upload H2D + phx_run + phx_download_flat D2H%s), %d timed steps, barrier + synchronize around them, max over ranks" % ("" if world == 1 else " + gather of the flat gene arrays to rank 0", args.steps),
             },
             "roofline": {
                 "bound": "hbm",
@@ -169,30 +312,45 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": pmc_traffic(dom, C_, L_),
+                "traffic": pmc_traffic(dom, len(seqs), L_) if args.workload == "synthetic" else None,
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this process)",
                 "algorithmic_bytes_per_launch": int(balgo),
                 "avg_launch_ms": round(dom_ms, 4),
+                "step_frac": round(step_achieved / HBM_PEAK_GBS, 6),
+                "step_achieved": round(step_achieved, 3),
+                "step_kernel_ms": round(kernel_ms_per_step, 4),
+                "step_frac_is": "SURVEY.md §8(d): sum of algorithmic bytes / sum of kernel time of one step (all stages, HIP events), / peak",
             },
             "stage_ms_per_step": {k: round(v[0] / 3, 4) for k, v in stages_all.items() if v[1] > 0},
-            "pcie_inclusive_Mbp_s": round(float(sz["L"]) / t_e2e / 1e6, 3),
         }
-        if not args.no_cpu and world == 1:
-            from oracle import oracle
-
-            ns = max(1, min(args.cpu_contigs, C_))
-            oracle.lib()
-            t0 = time.perf_counter()
-            for i in range(ns):
-                r = oracle.run(seqs[i])
-                assert r["status"] == 0
-            tc = time.perf_counter() - t0
-            out["cpu_baseline"] = {
-                "value": round(ns * L_ / tc / 1e6, 4),
-                "unit": "Mbp/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": "first %d of the %d contigs of this batch, C oracle (oracle/phx_oracle.c), %.1f s" % (ns, C_, tc),
-            }
+        ref = reference_python_rate()
+        if ref:
+            out["reference_python"] = ref
+        if world == 1 and not args.no_extras:
+            if args.workload == "synthetic":
+                single = {}
+                for key, case in SINGLE.items():  # configs 2 and 3: one contig, resident, 20 runs
+                    s1 = read_golden_fasta(case)
+                    a1 = pa.Annotator(device=local_rank)
+                    (st1, g1), = a1.annotate([s1])
+                    for _ in range(3):
+                        a1.run()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        a1.run()
+                    t1 = (time.perf_counter() - t0) / 20
+                    gl = a1.globals(0)
+                    single[key] = {"contig": case, "bp": len(s1), "ms_per_contig": round(t1 * 1e3, 4), "Mbp_s": round(len(s1) / t1 / 1e6, 2), "genes": int(len(g1)),
+                                   "int_limbs": int(gl.n_limbs), "solver_kernel": int(gl.sssp_kernel), "status": int(st1)}
+                    a1.close()
+                out["single_contig"] = single
+            if not args.no_cpu:
+                one, allc = cpu_baselines(seqs, L_, args.cpu_contigs if args.workload == "synthetic" else 1, args.cpu_per_core)
+                out["cpu_baseline"] = one
+                out["cpu_baseline_all_cores"] = allc
+            if args.cli_contigs > 0 and args.workload == "synthetic":
+                out["cli_end_to_end"] = cli_end_to_end(seqs[: args.cli_contigs], local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

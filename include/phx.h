@@ -38,6 +38,7 @@ extern "C" {
 #define PHX_E_NOMEM (-12)
 #define PHX_E_STATE (-13) /* call sequence error (e.g. run before upload) */
 #define PHX_E_PARAM (-14) /* codon tables must be 3 letters of acgt; 1..16 starts/stops; minlen >= 6 */
+#define PHX_E_IO (-15)    /* a file could not be opened or read */
 
 /* per-contig status (phx_result.status); the reference's behaviour in brackets */
 #define PHX_S_OK 0
@@ -207,6 +208,24 @@ int phx_synth_contig(uint64_t seed, int64_t L, char *out);
 /* The 4096-entry leftward-6-mer RBS score table the position kernel uses (4 offset classes packed
  * in one uint32, class A=offsets 3-4 in bits 0-7, B=5-10, C=11-12, D=13-15); for CPU-side tests. */
 int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t *t4 /* [256] */, uint32_t *t3 /* [64] */);
+
+/* ---- host I/O of the CLI (no device needed; phx_host.c) ---- */
+/* FASTA, plain or gzip, read whole: what phanotate.py:32-35 gets from the external `genbank` package.  A record's name is the
+ * first token of its header line (README.md:45); sequence lines are stripped of surrounding white space and joined, case kept
+ * (the kernels lower-case); text before the first header is ignored. */
+typedef struct phx_fasta phx_fasta;
+int phx_fasta_read(const char *path, phx_fasta **out);
+int32_t phx_fasta_count(const phx_fasta *f);
+/* name: NUL-terminated; seq: *len characters, NOT terminated; both owned by f */
+int phx_fasta_record(const phx_fasta *f, int32_t i, const char **name, const char **seq, int64_t *len);
+/* all records at once, in the form phx_upload / phx_format_tabular take (any array may be NULL) */
+int phx_fasta_arrays(const phx_fasta *f, const char **names, const char **seqs, int64_t *lens);
+void phx_fasta_free(phx_fasta *f);
+/* The reference's default output (Locus.tabular, locus.py:39-56) for n contigs from the flat arrays of phx_download_flat:
+ * "#id:\t<name>", the column header, then START STOP FRAME CONTIG SCORE per gene ('%E' score; START > STOP on the reverse
+ * strand).  Contigs with a negative status are skipped.  *text is malloc'ed (NUL-terminated), release with phx_free_text. */
+int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *genes, const int64_t *offsets, const int32_t *status, char **text, int64_t *text_len);
+void phx_free_text(char *text);
 
 #ifdef __cplusplus
 }

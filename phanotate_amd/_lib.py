@@ -124,6 +124,13 @@ def lib():
         "phx_batch_sizes": (C.c_int, [vp, P(i64), P(i64), P(i64), P(i64)]),
         "phx_synth_contig": (C.c_int, [C.c_uint64, i64, C.c_char_p]),
         "phx_rbs_table": (C.c_int, [vp, vp, vp, vp]),
+        "phx_fasta_read": (C.c_int, [C.c_char_p, P(vp)]),
+        "phx_fasta_count": (i32, [vp]),
+        "phx_fasta_record": (C.c_int, [vp, i32, P(vp), P(vp), P(i64)]),
+        "phx_fasta_arrays": (C.c_int, [vp, vp, vp, vp]),
+        "phx_fasta_free": (None, [vp]),
+        "phx_format_tabular": (C.c_int, [i32, vp, vp, vp, vp, P(vp), P(i64)]),
+        "phx_free_text": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
@@ -137,4 +144,5 @@ def lib():
 EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_create_ex", "phx_destroy",
            "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_run", "phx_download", "phx_download_flat", "phx_tap_globals",
            "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
-           "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table"]
+           "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table", "phx_fasta_read", "phx_fasta_count",
+           "phx_fasta_record", "phx_fasta_arrays", "phx_fasta_free", "phx_format_tabular", "phx_free_text"]

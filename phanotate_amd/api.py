@@ -99,6 +99,14 @@ class Annotator:
         self._chk(self.L.phx_upload(self.h, n, arr, lens), "phx_upload")
         self.n = n
 
+    def upload_raw(self, ptrs, lens, keep=None):
+        """The same from raw addresses: ptrs uint64[n] (host memory that stays valid for the call), lens int64[n]."""
+        ptrs = np.ascontiguousarray(ptrs, np.uint64)
+        lens = np.ascontiguousarray(lens, np.int64)
+        self._keep = (ptrs, lens, keep)
+        self._chk(self.L.phx_upload(self.h, len(lens), C.cast(ptrs.ctypes.data, C.POINTER(C.c_char_p)), C.cast(lens.ctypes.data, C.POINTER(C.c_int64))), "phx_upload")
+        self.n = len(lens)
+
     def attach(self, dev_ptr, offsets):
         """Concatenated ASCII already in HBM (e.g. a torch uint8 tensor's data_ptr()); offsets has n+1 entries."""
         offs = (C.c_int64 * len(offsets))(*[int(x) for x in offsets])
@@ -109,8 +117,9 @@ class Annotator:
     def run(self):
         self._chk(self.L.phx_run(self.h), "phx_run")
 
-    def download(self):
-        """[(status, genes structured array)] per contig; the arrays are views into one flat buffer (phx_download_flat)."""
+    def download_flat(self):
+        """(status int32[n], offsets int64[n+1], genes structured array[total]): genes of contig i are genes[offsets[i]:offsets[i+1]]
+        in path order (phx_download_flat: no per-contig allocation)."""
         n = self.n
         offs = np.zeros(n + 1, np.int64)
         status = np.zeros(max(n, 1), np.int32)
@@ -119,15 +128,26 @@ class Annotator:
         self._chk(self.L.phx_download_flat(self.h, None, 0, vp(offs), vp(status), C.byref(total)), "phx_download_flat")
         genes = np.zeros(max(int(total.value), 1), _lib.GENE_DT)
         self._chk(self.L.phx_download_flat(self.h, vp(genes), len(genes), vp(offs), vp(status), C.byref(total)), "phx_download_flat")
+        return status[:n], offs, genes[: int(total.value)]
+
+    def download(self):
+        """[(status, genes structured array)] per contig; the arrays are views into one flat buffer (phx_download_flat)."""
+        status, offs, genes = self.download_flat()
         o = offs.tolist()
         st = status.tolist()
-        return [(st[i], genes[o[i]:o[i + 1]]) for i in range(n)]
+        return [(st[i], genes[o[i]:o[i + 1]]) for i in range(self.n)]
 
     def annotate(self, seqs):
         """[(status, genes structured array)] for every contig, in input order."""
         self.upload(seqs)
         self.run()
         return self.download()
+
+    def annotate_flat(self, seqs):
+        """The same as three flat arrays, see download_flat."""
+        self.upload(seqs)
+        self.run()
+        return self.download_flat()
 
     # ---- stage taps (parity tests) ----
     def globals(self, i):

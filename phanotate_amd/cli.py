@@ -12,8 +12,6 @@ import sys
 
 from . import __version__
 from .api import Annotator, make_params
-from .fasta import read_fasta
-from .shard import run_sharded
 from .writers import FORMATS, write
 
 STATUS_TEXT = {-2: "letter outside the nucleotide alphabet (the reference raises KeyError)", -3: "contig shorter than 6 bases",
@@ -75,12 +73,47 @@ def dump_edges(out, ann, i):
         out.write("%s\t%s\t%s\n" % (rep(s), rep(d), repr(w * 1000)))
 
 
+def format_tabular(names, status, offsets, genes):
+    """locus.py:39-56 for a run of contigs, as bytes (libphx's phx_format_tabular)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+
+    L = _lib.lib()
+    n = len(names)
+    enc = [x.encode() for x in names]
+    arr = (C.c_char_p * max(n, 1))(*enc)
+    status = np.ascontiguousarray(status, np.int32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    genes = np.ascontiguousarray(genes)
+    text, tlen = C.c_void_p(), C.c_int64()
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    rc = L.phx_format_tabular(n, arr, vp(genes), vp(offsets), vp(status), C.byref(text), C.byref(tlen))
+    if rc:
+        raise _lib.PhxError(rc, "phx_format_tabular")
+    out = C.string_at(text.value, tlen.value)
+    L.phx_free_text(text)
+    return out
+
+
 def main(argv=None):
+    import json
+    import time
+
+    import numpy as np
+
+    from .fasta import Fasta
+    from .shard import partition, run_sharded_flat
+
+    t_start = time.perf_counter()
     args = get_args(argv)
-    records = read_fasta(args.infile)
-    if not records or not any(s for _, s in records):
+    fa = Fasta(args.infile)
+    if not len(fa) or not int(fa.lens.sum()):
         sys.stdout.write("Error: no sequences found in infile\n")  # phanotate.py:33-35
         return 0
+    t_parsed = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,34 +126,63 @@ def main(argv=None):
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     params = make_params(args.start_codons, args.stop_codons, args.min_orf_len)
     ann = Annotator(params, device=device)
-    seqs = [s for _, s in records]
     if args.dump:  # the reference dumps the first contig's edges and exits (phanotate.py:58-61)
-        ann.annotate(seqs[:1])
+        ann.upload_raw(fa.ptrs[:1], fa.lens[:1], fa)
+        ann.run()
         dump_edges(args.outfile, ann, 0)
         return 0
 
-    def annotate(batch):
-        out, cur, size = [], [], 0
-        for s in batch:
-            if cur and size + len(s) > args.batch_bases:
-                out.extend(ann.annotate(cur))
-                cur, size = [], 0
-            cur.append(s)
-            size += len(s)
-        if cur:
-            out.extend(ann.annotate(cur))
-        return out
+    n_total = len(fa)
+    mine = list(range(n_total)) if world == 1 else partition(fa.lens.tolist(), world)[rank]
 
-    results = run_sharded(seqs, annotate, rank, world, dist)
+    def annotate_flat(idx):  # this rank's contigs, in batches of --batch-bases, straight from the C buffer of the FASTA reader
+        idx = np.asarray(idx, np.int64)
+        parts, lo = [], 0
+        while lo < len(idx) or not parts:
+            hi, size = lo, 0
+            while hi < len(idx) and (hi == lo or size + int(fa.lens[idx[hi]]) <= args.batch_bases):
+                size += int(fa.lens[idx[hi]])
+                hi += 1
+            ann.upload_raw(fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa)
+            ann.run()
+            parts.append(ann.download_flat())
+            lo = hi
+            if lo >= len(idx):
+                break
+        if len(parts) == 1:
+            return parts[0]
+        st = np.concatenate([p[0] for p in parts])
+        genes = np.concatenate([p[2] for p in parts])
+        counts = np.concatenate([np.diff(p[1]) for p in parts])
+        return st, np.concatenate([[0], np.cumsum(counts)]).astype(np.int64), genes
+
+    merged = run_sharded_flat(mine, annotate_flat, rank, world, dist, mine=(mine, n_total))
+    t_gpu = time.perf_counter()
     rc = 0
+    t_fmt = t_gpu
     if rank == 0:
-        for (name, seq), (status, genes) in zip(records, results):
-            if status < 0:
-                sys.stderr.write("Error: contig %s: %s\n" % (name, STATUS_TEXT.get(status, "status %d" % status)))
-                rc = 1
-                continue
-            write(args.outfile, args.format, name, seq, genes)
+        status, offsets, genes = merged
+        for i in np.nonzero(status < 0)[0]:
+            sys.stderr.write("Error: contig %s: %s\n" % (fa.names[i], STATUS_TEXT.get(int(status[i]), "status %d" % int(status[i]))))
+            rc = 1
+        if args.format == "tabular":
+            text = format_tabular(fa.names, status, offsets, genes)
+            t_fmt = time.perf_counter()
+            args.outfile.flush()
+            if hasattr(args.outfile, "buffer"):
+                args.outfile.buffer.write(text)
+            else:
+                args.outfile.write(text.decode())
+        else:
+            for i in range(n_total):
+                if status[i] >= 0:
+                    write(args.outfile, args.format, fa.names[i], fa.seq(i).decode(), genes[offsets[i] : offsets[i + 1]])
+            t_fmt = time.perf_counter()
         args.outfile.flush()
+    t_end = time.perf_counter()
+    if os.environ.get("PHX_CLI_TIMING") and rank == 0:
+        sys.stderr.write("PHX_CLI_TIMING " + json.dumps({"parse_s": round(t_parsed - t_start, 4), "gpu_s": round(t_gpu - t_parsed, 4), "format_s": round(t_fmt - t_gpu, 4),
+                                                         "write_s": round(t_end - t_fmt, 4), "total_s": round(t_end - t_start, 4), "bases": int(fa.lens.sum()), "genes": int(len(merged[2]))}) + "\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -366,6 +366,7 @@ const char *phx_strerror(int code) {
     case PHX_E_NOMEM: return "out of memory";
     case PHX_E_STATE: return "call sequence error";
     case PHX_E_PARAM: return "bad codon table / minlen";
+    case PHX_E_IO: return "file could not be opened or read";
     case PHX_S_BADLETTER: return "letter outside the IUPAC nucleotide alphabet";
     case PHX_S_TOOSHORT: return "contig shorter than 6 bases";
     case PHX_S_PARALLEL: return "bridge edge duplicates a connect edge";

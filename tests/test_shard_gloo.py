@@ -27,9 +27,29 @@ WORKER = textwrap.dedent(
     assert calls == [len(parts[rank])]
     if rank == 0:
         assert out == [(0, hashlib.md5(s).hexdigest()) for s in seqs]
-        print("SHARD_OK", [len(p) for p in parts])
     else:
         assert out is None
+    # the flat protocol (three arrays per rank instead of one object per contig): bench.py's and the CLI's N > 1 path
+    import numpy as np
+    from phanotate_amd.shard import run_sharded_flat
+    from phanotate_amd import _lib
+    def fake_flat(batch):
+        cnt = [len(s) %% 5 for s in batch]
+        g = np.zeros(sum(cnt), _lib.GENE_DT)
+        g["left"] = np.concatenate([np.full(c, len(s)) + np.arange(c) for s, c in zip(batch, cnt)]) if sum(cnt) else []
+        return np.array([len(s) %% 3 - 1 for s in batch], np.int32), np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64), g
+    flat = run_sharded_flat(seqs, fake_flat, rank, world, dist)
+    mine = parts[rank]
+    flat2 = run_sharded_flat([seqs[i] for i in mine], fake_flat, rank, world, dist, mine=(mine, len(seqs)))
+    if rank == 0:
+        for st, offs, g in (flat, flat2):
+            assert st.tolist() == [len(s) %% 3 - 1 for s in seqs]
+            assert np.diff(offs).tolist() == [len(s) %% 5 for s in seqs]
+            for i, s in enumerate(seqs):
+                assert g["left"][offs[i]:offs[i + 1]].tolist() == [len(s) + k for k in range(len(s) %% 5)]
+        print("SHARD_OK", [len(p) for p in parts])
+    else:
+        assert flat is None and flat2 is None
     dist.barrier()
     dist.destroy_process_group()
     """
