@@ -127,6 +127,12 @@ typedef struct phx_globals {
                                * 2 spill list full, 3 no convergence, 4 too many step-backs */
     int32_t tie; /* equal-length alternatives to the shortest path (the reference's relaxation order decides, see phx_inorder.inc):
                   * 0 none, 1 they exist and the solver's path already was the reference's, 2 the path was replaced by the reference's */
+    /* the integer counters behind the fp64 globals above (what a Decimal restatement of the reference starts from, see
+     * phanotate_amd/dump.py): RBS bin counts without the pseudo-count (functions.py:155-156,168-169,211), GC-frame training
+     * counts (functions.py:261-279, index 1..3), g+c over the contig after the counting remap of functions.py:159-163 */
+    uint32_t rbs_background_count[28], rbs_training_count[28];
+    uint32_t gc_max_count[4], gc_min_count[4];
+    int64_t gc_count;
 } phx_globals;
 
 /* ---- library ---- */

@@ -37,6 +37,8 @@ class Globals(C.Structure):
         ("n_orf", C.c_int32), ("n_group", C.c_int32), ("n_node", C.c_int32), ("n_edge", C.c_int32), ("n_bridge", C.c_int32),
         ("n_limbs", C.c_int32), ("sssp_sweeps", C.c_int32), ("sssp_iters", C.c_int32), ("status", C.c_int32),
         ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32), ("tie", C.c_int32),
+        ("rbs_background_count", C.c_uint32 * 28), ("rbs_training_count", C.c_uint32 * 28), ("gc_max_count", C.c_uint32 * 4), ("gc_min_count", C.c_uint32 * 4),
+        ("gc_count", C.c_int64),
     ]
 
 

@@ -40,9 +40,16 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
-def dump_edges(out, ann, i):
-    """-d/--dump (phanotate.py:58,61): one line per edge, repr(src) TAB repr(dst) TAB weight*1000, in the
-    reference's Graph.iteredges order.  Weights are fp64 here, Decimal (28 digits) in the reference."""
+def dump_edges(out, ann, i, seq=None, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
+    """-d/--dump (phanotate.py:58,61): one line per edge, repr(src) TAB repr(dst) TAB str(weight*1000), in the reference's
+    Graph.iteredges order.  With the contig's sequence the weights are the reference's 28-digit Decimal values (dump.py);
+    without it (get_graph of the mirror module) they are the device's fp64 values."""
+    if seq is not None:
+        from .dump import dump_lines
+
+        for line in dump_lines(ann, i, seq, start_codons):
+            out.write(line + "\n")
+        return
     nd = ann.nodes(i)
     ed = ann.edges(i)
     tname = {0: "start", 1: "stop", 2: "source", 3: "target"}
@@ -53,7 +60,6 @@ def dump_edges(out, ann, i):
         return "Node(%r,%r,%r,%r)" % (gene, tname[int(n["type"])], int(n["frame"]), int(n["pos"]))
 
     ref = nd["refidx"]
-    V = len(nd)
     keyed = []
     for e in ed:
         s, d = int(e["src"]), int(e["dst"])
@@ -129,7 +135,7 @@ def main(argv=None):
     if args.dump:  # the reference dumps the first contig's edges and exits (phanotate.py:58-61)
         ann.upload_raw(fa.ptrs[:1], fa.lens[:1], fa)
         ann.run()
-        dump_edges(args.outfile, ann, 0)
+        dump_edges(args.outfile, ann, 0, fa.seq(0), args.start_codons)
         return 0
 
     n_total = len(fa)

@@ -953,6 +953,9 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->sssp_kernel = m.sssp_mode;
     out->sssp_handed_back = m.sssp_why > 0 ? m.sssp_why : 0;
     out->tie = m.tie;
+    for (int i = 0; i < 28; i++) { out->rbs_background_count[i] = m.bg[i]; out->rbs_training_count[i] = m.tr[i]; }
+    for (int i = 0; i < 4; i++) { out->gc_max_count[i] = i ? m.pmax[i] : 0u; out->gc_min_count[i] = i ? m.pmin[i] : 0u; }
+    out->gc_count = m.gc;
     return PHX_OK;
 }
 

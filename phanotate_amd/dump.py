@@ -1,0 +1,160 @@
+"""-d/--dump (phanotate.py:58,61): one line per edge of the first contig's graph,
+    repr(source) TAB repr(target) TAB str(weight*1000)                      (edges.py:17-23, nodes.py:14-21)
+in Graph.iteredges order, with the reference's 28-digit Decimal weights, so that the text can be diffed against an
+upstream install line by line.
+
+The GPU computes the weights in fp64; Decimal text cannot be printed from those.  What the GPU path does deliver exactly is
+every INTEGER the reference's arithmetic starts from: the ORF table in iter_orfs order (start, stop, frame, RBS bin, start
+codon), the GC-frame class of every codon (phx_tap_positions), the RBS / GC-frame training counters and the g+c count
+(phx_tap_globals), other_end, and the node and edge lists.  This module replays the reference's Decimal operations on them,
+operation by operation and in the same order (Decimal rounds after every operation, so the order matters):
+functions.py:174-178 (pstop), orfs.py:162-173 (Orf.p_stop), functions.py:254-257, 281-301 + orfs.py:122-127 (ORF weight),
+functions.py:26-46 (score_overlap / score_gap), functions.py:373-385 (o1, o2), and the branch of functions.py:334-452 that
+created each edge.  It is host-side formatting of one contig, not part of the per-batch path.
+"""
+from decimal import Decimal
+
+import numpy as np
+
+TNAME = {0: "start", 1: "stop", 2: "source", 3: "target"}
+
+
+def start_weights(start_codons):
+    """file_handling.py:58-62: codon -> Decimal(weight) / max."""
+    w = {}
+    for item in start_codons.split(","):
+        codon, weight = item.split(":")
+        w[codon.lower()] = Decimal(weight)
+    m = max(w.values())
+    return {k: v / m for k, v in w.items()}
+
+
+def _overlap(length, diff, pstop):  # functions.py:26-34
+    score = 1 / (Decimal(Decimal(1 - pstop)) ** Decimal(length))
+    return score + 1 / Decimal("0.05") if diff else score
+
+
+def _gap(length, diff, pgap):  # functions.py:36-46
+    g = Decimal(1 - pgap)
+    if length > 300:
+        return Decimal(g) ** Decimal(100) + length
+    score = 1 / (Decimal(g) ** Decimal(length / 3))
+    return score + 1 / Decimal("0.05") if diff else score
+
+
+def orf_weights(seq, orf, gcc, gl, weights, start_names):
+    """Decimal pstop and weight of every ORF of the tap `orf` (reference order)."""
+    dna = seq.lower()
+    comp = {"a": "t", "t": "a", "g": "c", "c": "g"}
+    # functions.py:281-284
+    pos_max = [Decimal(1) + int(gl.gc_max_count[k]) for k in range(4)]
+    pos_min = [Decimal(1) + int(gl.gc_min_count[k]) for k in range(4)]
+    y = max(pos_max)
+    pos_max = [x / y for x in pos_max]
+    y = max(pos_min)
+    pos_min = [x / y for x in pos_min]
+    fwd_cls = (gcc & 15).tolist()
+    rev_cls = (gcc >> 4).tolist()
+    pstops, out = [], []
+    for r in orf:
+        start, stop, frame = int(r["start"]), int(r["stop"]), int(r["frame"])
+        # Orf.p_stop on the coding strand (orfs.py:162-173); letters outside acgt only count in the length
+        s = dna[start - 1 : stop + 2] if frame > 0 else dna[stop - 1 : start + 2]
+        na, nt, ng = s.count("a"), s.count("t"), s.count("g")
+        if frame < 0:
+            na, nt, ng = nt, na, s.count("c")
+        length = Decimal(len(s))
+        Pa, Pt, Pg = na / length, nt / length, ng / length
+        pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg
+        pstops.append(pstop)
+        # functions.py:286-298: hold *= ((1-pstop)**pos_max[imax])**pos_min[imin] per sense codon; the factor only depends on
+        # the codon's class, the running product is rounded after every multiplication as in the reference
+        fac = {}
+        hold = 1
+        one_minus = 1 - pstop
+        if frame > 0:
+            classes = fwd_cls[start - 1 : stop - 1 : 3]
+        else:
+            classes = rev_cls[start - 1 : stop - 1 : -3]
+        for c in classes:
+            f = fac.get(c)
+            if f is None:
+                f = fac[c] = (one_minus ** pos_max[c // 3 + 1]) ** pos_min[c % 3 + 1]
+            hold = hold * f
+        # Orf.score, orfs.py:122-127
+        w = 1 / hold
+        k = int(r["startidx"])
+        if k >= 0:
+            w = w * weights[start_names[k]]
+        b = int(r["rbs"])
+        w = w * Decimal(str(gl.training_rbs[b] / gl.background_rbs[b]))
+        out.append(-w)
+    return pstops, out
+
+
+def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
+    """The --dump text of contig i of the batch `ann` last ran, as a list of lines (no newline)."""
+    if isinstance(seq, (bytes, bytearray)):
+        seq = seq.decode()
+    gl = ann.globals(i)
+    L = int(gl.L)
+    nd, ed, orf = ann.nodes(i), ann.edges(i), ann.orfs(i)
+    gcc = ann.positions(i)["gcc"]
+    weights = start_weights(start_codons)
+    start_names = list(weights.keys())
+    # functions.py:174-178: both strands are counted, so a == t and g == c
+    fa, fg = Decimal(L - int(gl.gc_count)), Decimal(int(gl.gc_count))
+    Pa, Pt, Pg = fa / (L * 2), fa / (L * 2), fg / (L * 2)
+    pgap = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg
+    opstop, oweight = orf_weights(seq, orf, gcc, gl, weights, start_names)
+    by_stop = {}
+    for k, r in enumerate(orf):
+        by_stop.setdefault(int(r["stop"]), {})[int(r["start"])] = k
+    other_end = {int(n["pos"]): int(n["other"]) for n in nd if n["type"] < 2}
+
+    def o_term(p):  # functions.py:373-384
+        if p in by_stop and other_end[p] in by_stop[p]:
+            return opstop[by_stop[p][other_end[p]]]
+        if p in by_stop:
+            q = other_end[p]
+            if q in by_stop and p in by_stop[q]:
+                return opstop[by_stop[q][p]]
+            return pgap  # (the reference raises here; libphx reports such a contig through its status)
+        return pgap
+
+    def rep(v):
+        n = nd[v]
+        t = TNAME[int(n["type"])]
+        return "Node(%r,%r,%r,%r)" % ("CDS" if n["type"] < 2 else t, t, int(n["frame"]), int(n["pos"]))
+
+    ref = nd["refidx"]
+    keyed = []
+    for e in ed:
+        s, d = int(e["src"]), int(e["dst"])
+        ts, td = int(nd[s]["type"]), int(nd[d]["type"])
+        fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
+        ps, pd = int(nd[s]["pos"]), int(nd[d]["pos"])
+        if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
+            # ORF edge start -> stop / stop -> start (functions.py:311-318)
+            start, stop = (ps, pd) if fs > 0 else (pd, ps)
+            w = oweight[by_stop[stop][start]]
+            k = (0, int(ref[d]), 0)
+        elif ts == 2:  # functions.py:445-448
+            w = _gap(pd, False, pgap)
+            k = (3, int(ref[d]), 0)
+        elif td == 3:  # functions.py:449-452
+            w = _gap(L - ps, False, pgap)
+            k = (3, int(ref[d]), 0)
+        else:
+            diff = fs * fd < 0
+            if ps < pd:  # left -> right: a gap edge of the connect loop, or a bridge over a non-coding run (same formula)
+                w = _gap(pd - ps - 3, diff, pgap)
+                l, r = s, d
+            else:  # right -> left: overlap edge, pstop = ave([o1, o2]) (functions.py:385)
+                l, r = d, s
+                pst = Decimal((o_term(int(nd[l]["pos"])) + o_term(int(nd[r]["pos"]))) / 2)
+                w = _overlap(ps - pd + 3, diff, pst)
+            k = (1 if abs(ps - pd) >= 500 else 2, int(ref[r]), int(ref[l]))  # the loops run right node outer, left node inner
+        keyed.append((int(ref[s]), k, s, d, w))
+    keyed.sort(key=lambda t: (t[0], t[1]))
+    return ["%s\t%s\t%s" % (rep(s), rep(d), str(w * 1000)) for _, _, s, d, w in keyed]

@@ -310,8 +310,8 @@ def test_solver_alone_exact_integers(pa, bits, nl):
 
 
 def test_cli_tabular_and_dump(pa, tmp_path):
-    """phanotate.py end to end: multi-contig FASTA in, the reference's tabular text out; and -d/--dump in the
-    reference's Graph.iteredges order (weights compared numerically: Decimal text cannot be reproduced in fp64)."""
+    """phanotate.py end to end: multi-contig FASTA in, the reference's tabular text out; and -d/--dump: the reference's
+    edge text (Graph.iteredges order, Decimal weights), checked against the fixtures' md5 of that text."""
     import gzip
     import re
     import subprocess
@@ -347,6 +347,9 @@ def test_cli_tabular_and_dump(pa, tmp_path):
             assert (tcode[ms.group(2)], int(ms.group(3)), int(ms.group(4))) == (int(g["node_type"][si]), int(g["node_frame"][si]), int(g["node_pos"][si])), (c, k)
             assert (tcode[md.group(2)], int(md.group(3)), int(md.group(4))) == (int(g["node_type"][di]), int(g["node_frame"][di]), int(g["node_pos"][di])), (c, k)
             assert abs(float(w) / (float(g["edge_weight"][k]) * 1000) - 1) < 1e-9
+        import hashlib
+
+        assert hashlib.md5(r.stdout.encode()).hexdigest() == str(g["dump_md5"]), c
 
 
 class _Locus:
@@ -761,4 +764,29 @@ def test_solver_alone_ties_follow_the_callers_edge_order(pa):
         assert path == want, (trial, V)
         checked += 1
     assert checked > 150
+    ann.close()
+
+
+@pytest.mark.parametrize("case", [c for c in golden_cases()])
+def test_dump_text_is_byte_exact(case, pa):
+    """-d/--dump: the edge text of the reference (edges.py:17-23: repr(src), repr(dst), str(Decimal weight * 1000), in
+    Graph.iteredges order), reproduced byte for byte: phanotate_amd/dump.py replays the reference's Decimal operations on the
+    integers the GPU path delivers.  The fixtures hold the md5 of the reference's own text."""
+    import hashlib
+
+    from phanotate_amd.dump import dump_lines
+
+    g, name, seq = load_golden(case)
+    if str(g["error"]):
+        pytest.skip("the reference raises on this input")
+    kw = golden_params(g)
+    ann = pa.Annotator(pa.make_params(**kw))
+    (status, genes), = ann.annotate([seq])
+    assert status >= 0
+    lines = dump_lines(ann, 0, seq, kw["start_codons"])
+    assert len(lines) == len(g["edge_src"])
+    h = hashlib.md5()
+    for line in lines:
+        h.update((line + "\n").encode())
+    assert h.hexdigest() == str(g["dump_md5"])
     ann.close()
