@@ -70,7 +70,8 @@ typedef struct phx_gene {
     int32_t left;
     int32_t right;
     int32_t strand; /* +1 / -1 */
-    int32_t frame;  /* reference Node.frame of the ORF: +-1..3 */
+    int32_t frame;  /* reference Node.frame of the left node: +-1..3 for a CDS, +-4 for a tRNA (left.gene == 'tRNA', phanotate.py:75;
+                     * Locus.tabular prints CDS features only, locus.py:42) */
     double score;   /* ORF edge weight, what the reference prints with '%E' */
 } phx_gene;
 
@@ -99,9 +100,9 @@ typedef struct phx_orf {
 typedef struct phx_node {
     int32_t pos;
     int8_t type;  /* 0 start, 1 stop, 2 source, 3 target */
-    int8_t frame; /* +-1..3, 0 for source/target */
+    int8_t frame; /* +-1..3 CDS, +-4 tRNA (Node.gene == 'tRNA', functions.py:500-505), 0 for source/target */
     int16_t pad;
-    int32_t other; /* Orfs.other_end[pos] as seen by get_graph (functions.py:363,369); -1 for source/target */
+    int32_t other; /* Orfs.other_end[pos] (tRNA nodes: other_end['t' + str(pos)]) as seen by get_graph (functions.py:363-371); -1 for source/target */
     int32_t refidx; /* rank of this node in the reference's Graph.iternodes() order */
     double o;      /* the o1/o2 term of functions.py:373-384 for this position */
 } phx_node;
@@ -165,6 +166,14 @@ void phx_free_results(phx_result *res, int32_t n);
 int phx_upload(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *len); /* H2D of ASCII */
 /* Alternative to phx_upload: the concatenated ASCII is already in device memory (offsets on host, n+1 entries). */
 int phx_attach(phx_ctx *ctx, int32_t n, const void *d_ascii, const int64_t *offsets);
+/* tRNA masking (functions.add_trnas, functions.py:457-509): the hits of an external tRNA finder for the contigs of the batch just
+ * uploaded / attached, as the reference holds them in `trnas`: hits of contig i are (start[k], stop[k]) for k in
+ * [offsets[i], offsets[i+1]); start < stop for a hit on the forward strand, start > stop (the pair reversed) for a complement hit;
+ * 1-based, inside the contig.  The device then adds the tRNA nodes (frame +-4), their edges of weight -20 and the connect rules
+ * of functions.py:388-399.  Call after phx_upload / phx_attach and before phx_run; a new upload forgets the hits.  Not calling
+ * it (or offsets == NULL) is "no tRNA finder installed" (functions.py:493-495).  Running the finders is the caller's business
+ * (phanotate_amd/trna.py does what functions.py:457-491 does). */
+int phx_set_trnas(phx_ctx *ctx, const int64_t *offsets /* [n+1] */, const int32_t *start, const int32_t *stop);
 int phx_run(phx_ctx *ctx);                        /* every kernel of the path; blocks until results are in HBM */
 int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] */
 /* The same into caller-owned flat arrays (what a language binding wants: no per-contig allocation): genes of contig i are

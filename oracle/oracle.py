@@ -42,7 +42,7 @@ class Edge(C.Structure):
 
 
 class Gene(C.Structure):
-    _fields_ = [("left", C.c_int32), ("right", C.c_int32), ("strand", C.c_int32), ("score", C.c_double)]
+    _fields_ = [("left", C.c_int32), ("right", C.c_int32), ("strand", C.c_int32), ("frame", C.c_int32), ("score", C.c_double)]
 
 
 class Result(C.Structure):
@@ -59,6 +59,7 @@ class Result(C.Structure):
         ("dist", C.c_uint64 * 4), ("bf_rounds", C.c_int32),
         ("n_gene", C.c_int32), ("gene", C.POINTER(Gene)),
         ("binF", C.POINTER(C.c_uint8)), ("binR", C.POINTER(C.c_uint8)),
+        ("other_end_t", C.POINTER(C.c_int32)),
     ]
 
 
@@ -67,7 +68,7 @@ ORF_DT = np.dtype([("start", "i4"), ("stop", "i4"), ("frame", "i4"), ("length", 
                    ("pstop", "f8"), ("weight_rbs", "f8"), ("S", "f8"), ("weight", "f8")], align=True)
 EDGE_DT = np.dtype([("src", "i4"), ("dst", "i4"), ("w", "f8"), ("wint", "u8", (4,))], align=True)
 NODE_DT = np.dtype([("type", "i1"), ("frame", "i1"), ("pos", "i4")], align=True)
-GENE_DT = np.dtype([("left", "i4"), ("right", "i4"), ("strand", "i4"), ("score", "f8")], align=True)
+GENE_DT = np.dtype([("left", "i4"), ("right", "i4"), ("strand", "i4"), ("frame", "i4"), ("score", "f8")], align=True)
 
 _lib = None
 
@@ -85,6 +86,8 @@ def lib():
         _lib = C.CDLL(so)
         _lib.orc_run.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Params), C.c_int, C.POINTER(Result)]
         _lib.orc_run.restype = C.c_int
+        _lib.orc_run_trna.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Params), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Result)]
+        _lib.orc_run_trna.restype = C.c_int
         _lib.orc_free.argtypes = [C.POINTER(Result)]
         _lib.orc_sizeof_params.restype = C.c_size_t
         _lib.orc_score_rbs.argtypes = [C.c_char_p, C.c_int]
@@ -129,13 +132,19 @@ def limbs_to_int(limbs):
     return v - (1 << n) if v >> (n - 1) else v
 
 
-def run(seq, params=None, stages=3):
-    """Run the oracle on one contig; returns a dict of numpy arrays / scalars (copies)."""
+def run(seq, params=None, stages=3, trnas=None):
+    """Run the oracle on one contig; returns a dict of numpy arrays / scalars (copies).
+    trnas: None = no tRNA finder (functions.py:493-495), else the hit list [(start, stop)] add_trnas would hold (may be empty)."""
     if isinstance(seq, str):
         seq = seq.encode()
     params = params or make_params()
     r = Result()
-    lib().orc_run(seq, len(seq), C.byref(params), stages, C.byref(r))
+    if trnas is None:
+        lib().orc_run(seq, len(seq), C.byref(params), stages, C.byref(r))
+    else:
+        ts = np.ascontiguousarray([t[0] for t in trnas], np.int32)
+        te = np.ascontiguousarray([t[1] for t in trnas], np.int32)
+        lib().orc_run_trna(seq, len(seq), C.byref(params), stages, len(trnas), ts.ctypes.data_as(C.c_void_p), te.ctypes.data_as(C.c_void_p), C.byref(r))
     out = {"status": r.status, "L": r.L}
     if r.status == 0:
         L = r.L
@@ -152,6 +161,7 @@ def run(seq, params=None, stages=3):
         if stages >= 2:
             nd = _view(r.node, r.n_node, NODE_DT)
             out["node_type"], out["node_frame"], out["node_pos"] = nd["type"], nd["frame"], nd["pos"]
+            out["other_end_t"] = np.ctypeslib.as_array(r.other_end_t, (L + 4,)).copy()
             ed = _view(r.edge, r.n_edge, EDGE_DT)
             out["edge_src"], out["edge_dst"], out["edge_weight"] = ed["src"], ed["dst"], ed["w"]
             out["edge_wint_limbs"] = ed["wint"]
@@ -162,6 +172,7 @@ def run(seq, params=None, stages=3):
             ge = _view(r.gene, r.n_gene, GENE_DT)
             out["gene_left"], out["gene_right"] = ge["left"], ge["right"]
             out["gene_strand"], out["gene_score"] = ge["strand"].astype(np.int8), ge["score"]
+            out["gene_frame"] = ge["frame"].astype(np.int8)
     lib().orc_free(C.byref(r))
     return out
 

@@ -114,6 +114,21 @@ class Annotator:
         self._chk(self.L.phx_attach(self.h, len(offsets) - 1, C.c_void_p(int(dev_ptr)), offs), "phx_attach")
         self.n = len(offsets) - 1
 
+    def set_trnas(self, trnas):
+        """tRNA hits for the batch just uploaded: one list of (start, stop) per contig, as functions.add_trnas holds them
+        (start > stop for a complement hit); None = no tRNA finder installed (functions.py:493-495)."""
+        if trnas is None:
+            self._chk(self.L.phx_set_trnas(self.h, None, None, None), "phx_set_trnas")
+            return
+        if len(trnas) != self.n:
+            raise ValueError("one hit list per contig of the batch")
+        offs = np.zeros(self.n + 1, np.int64)
+        np.cumsum([len(t) for t in trnas], out=offs[1:])
+        a = np.ascontiguousarray([h[0] for t in trnas for h in t] or [0], np.int32)
+        z = np.ascontiguousarray([h[1] for t in trnas for h in t] or [0], np.int32)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.phx_set_trnas(self.h, vp(offs), vp(a), vp(z)), "phx_set_trnas")
+
     def run(self):
         self._chk(self.L.phx_run(self.h), "phx_run")
 
@@ -137,9 +152,11 @@ class Annotator:
         st = status.tolist()
         return [(st[i], genes[o[i]:o[i + 1]]) for i in range(self.n)]
 
-    def annotate(self, seqs):
-        """[(status, genes structured array)] for every contig, in input order."""
+    def annotate(self, seqs, trnas=None):
+        """[(status, genes structured array)] for every contig, in input order.  trnas: see set_trnas."""
         self.upload(seqs)
+        if trnas is not None:
+            self.set_trnas(trnas)
         self.run()
         return self.download()
 

@@ -132,8 +132,22 @@ def main(argv=None):
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     params = make_params(args.start_codons, args.stop_codons, args.min_orf_len)
     ann = Annotator(params, device=device)
+    import shutil
+
+    from .trna import find_trnas
+
+    have_finder = bool(shutil.which("aragorn") or shutil.which("tRNAscan-SE"))
+
+    def trnas_of(idx):  # functions.add_trnas per contig (functions.py:457-495); None: neither tool is installed
+        if not have_finder:
+            for _ in idx:
+                sys.stderr.write("Warning: tRNAscan or Aragorn were not found, proceding without tRNA masking.\n")
+            return None
+        return [find_trnas(fa.seq(int(i))) or [] for i in idx]
+
     if args.dump:  # the reference dumps the first contig's edges and exits (phanotate.py:58-61)
         ann.upload_raw(fa.ptrs[:1], fa.lens[:1], fa)
+        ann.set_trnas(trnas_of([0]))
         ann.run()
         dump_edges(args.outfile, ann, 0, fa.seq(0), args.start_codons)
         return 0
@@ -150,6 +164,7 @@ def main(argv=None):
                 size += int(fa.lens[idx[hi]])
                 hi += 1
             ann.upload_raw(fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa)
+            ann.set_trnas(trnas_of(idx[lo:hi]))
             ann.run()
             parts.append(ann.download_flat())
             lo = hi

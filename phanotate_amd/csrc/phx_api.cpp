@@ -81,6 +81,9 @@ struct phx_ctx {
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
+    DevBuf b_tnode, b_tedge, b_tnid, b_tbits; // tRNA masking (phx_set_trnas)
+    std::vector<DTNode> h_tnode;               // host copy for the node tap
+    bool has_trna = false;
     DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
     int64_t tie_seen = 0; // largest DTotals.tie_need a run reported
     DevBuf b_ekey;        // phx_solve: rank of every edge in the caller's order
@@ -281,6 +284,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
     b->bridge = (DBridge *)c->b_bridge.p;
+    if (c->has_trna) { b->tnode = (const DTNode *)c->b_tnode.p; b->tedge = (const DTEdge *)c->b_tedge.p; b->tnid = (int32_t *)c->b_tnid.p; b->tbits = (uint64_t *)c->b_tbits.p; }
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
     b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
     b->in_off = (uint32_t *)c->b_inoff.p;
@@ -299,6 +303,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
 
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
+    c->has_trna = false; c->h_tnode.clear();
     if (n < 0) return PHX_E_ARG;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
     c->tiles.clear();
@@ -461,7 +466,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -550,6 +555,66 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     return PHX_OK;
 }
 
+int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, const int32_t *stop) {
+    if (!c) return PHX_E_ARG;
+    if (!c->uploaded) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ran = false; c->graph_valid = false; c->meta0_dirty = true; c->runs_on_layout = 0;
+    c->has_trna = false; c->h_tnode.clear();
+    for (DMeta &m : c->meta) { m.n_tnode = 0; m.n_tedge = 0; m.tn_off = 0; m.te_off = 0; if (m.status == PHX_S_PARALLEL) m.status = 0; }
+    if (!offsets) return PHX_OK; // no tRNA finder: the graph is built without add_trnas' part (functions.py:493-495)
+    const int n = c->n;
+    if (offsets[0] != 0) return PHX_E_ARG;
+    for (int i = 0; i < n; i++) if (offsets[i + 1] < offsets[i]) return PHX_E_ARG;
+    if (offsets[n] > 0 && (!start || !stop)) return PHX_E_ARG;
+    std::vector<DTNode> tn;
+    std::vector<DTEdge> te;
+    for (int i = 0; i < n; i++) {
+        DMeta &m = c->meta[(size_t)i];
+        m.tn_off = (int64_t)tn.size(); m.te_off = (int64_t)te.size();
+        const size_t n0 = tn.size(), e0 = te.size();
+        std::vector<std::pair<int32_t, int32_t>> other; // other_end['t' + str(pos)]: last writer wins (functions.py:502-508)
+        auto set_other = [&](int32_t pos, int32_t v) { for (auto &o : other) if (o.first == pos) { o.second = v; return; } other.push_back({pos, v}); };
+        auto node = [&](int type, int frame, int32_t pos) -> int32_t { // Graph.add_node: an existing node is reused (nodes.py:7-12: identity = repr)
+            const int32_t info = NINFO(type, frame);
+            for (size_t k = n0; k < tn.size(); k++) if (tn[k].pos == pos && tn[k].info == info) return (int32_t)(k - n0);
+            tn.push_back(DTNode{pos, info, -1, (int32_t)(tn.size() - n0)});
+            return (int32_t)(tn.size() - 1 - n0);
+        };
+        bool parallel = false;
+        for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
+            const int32_t a = start[k], z = stop[k];
+            int32_t s, t;
+            if (a < z) { // functions.py:499-503
+                if (a < 1 || z - 2 < 1 || z - 2 > m.L) return PHX_E_ARG;
+                s = node(0, 4, a); t = node(1, 4, z - 2);
+                set_other(z - 2, a); set_other(a, z - 2);
+            } else { // functions.py:504-508
+                if (z < 1 || a - 2 < 1 || a - 2 > m.L || z > m.L) return PHX_E_ARG;
+                s = node(1, -4, z); t = node(0, -4, a - 2);
+                set_other(a - 2, z); set_other(z, a - 2);
+            }
+            for (size_t q = e0; q < te.size(); q++) if (te[q].src == s && te[q].dst == t) parallel = true;
+            te.push_back(DTEdge{s, t});
+        }
+        for (size_t k = n0; k < tn.size(); k++) for (auto &o : other) if (o.first == tn[k].pos) tn[k].other = o.second;
+        m.n_tnode = (int32_t)(tn.size() - n0); m.n_tedge = (int32_t)(te.size() - e0);
+        if (parallel) { m.status = PHX_S_PARALLEL; m.n_tedge = -1; } // the reference raises (graphs.py:74); marked for run_once
+    }
+    if (tn.empty()) return PHX_OK; // finders ran and found nothing: same graph as without
+    int rc;
+    if ((rc = ensure(c, c->b_tnode, sizeof(DTNode) * (tn.size() + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tedge, sizeof(DTEdge) * (te.size() + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tnid, 4 * (tn.size() + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tbits, (size_t)(c->tot_nbits / 3 * 4 + 8) * 8))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->b_tnode.p, tn.data(), sizeof(DTNode) * tn.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b_tedge.p, te.data(), sizeof(DTEdge) * te.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_tnode.swap(tn);
+    c->has_trna = true;
+    return PHX_OK;
+}
+
 int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offsets) {
     if (!c || n < 0 || !offsets || (n > 0 && !d_ascii)) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -581,6 +646,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     {
         StageTimer t(c, ST_MEMSET);
         HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
+        if (c->has_trna) HIPCHK(c, hipMemsetAsync(c->b_tbits.p, 0, (size_t)(c->tot_nbits / 3 * 4 + 8) * 8, s));
         HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
         HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
     }
@@ -732,6 +798,8 @@ int run_once(phx_ctx *c, bool learn) {
             memset(&m, 0, sizeof(m));
             m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
             m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
+            m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
+            if (k.status == PHX_S_PARALLEL && k.n_tedge < 0) { m.status = PHX_S_PARALLEL; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74)
         }
         HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -1050,8 +1118,10 @@ int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
         out[v].other = nd[v].other; out[v].o = no[v];
         // reference insertion rank (functions.py:311-318): per ORF (source, target) in iter_orfs order
         int ref = -1;
-        if (v + 2 == V) ref = m.n_orf + m.n_grp;
-        else if (v + 1 == V) ref = m.n_orf + m.n_grp + 1;
+        const int ntn = c->has_trna ? m.n_tnode : 0;
+        if (v + 2 == V) ref = m.n_orf + m.n_grp + ntn;
+        else if (v + 1 == V) ref = m.n_orf + m.n_grp + ntn + 1;
+        else if (LINK_KIND(nd[v].link) == LINK_TRNA) ref = m.n_orf + m.n_grp + c->h_tnode[(size_t)m.tn_off + LINK_IDX(nd[v].link)].rank; // add_trnas runs after every CDS node exists (functions.py:357)
         else if (LINK_KIND(nd[v].link) == LINK_STOP) {
             const size_t g = (size_t)LINK_IDX(nd[v].link);
             ref = ref_first[g] + ref_rank[g] + (grp[g].frame > 0 ? 1 : 0);

@@ -167,6 +167,7 @@ int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *gene
         memcpy(p, "#START\tSTOP\tFRAME\tCONTIG\tSCORE\n", 31); p += 31;
         for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
             const phx_gene *g = &genes[k];
+            if (g->frame == 4 || g->frame == -4) continue; /* a tRNA feature: Locus.tabular lists features(include=['CDS']), locus.py:42 */
             const int32_t a = g->strand < 0 ? g->right : g->left, z = g->strand < 0 ? g->left : g->right; /* locus.py:44-46 */
             p = put_int(p, a); *p++ = '\t';
             p = put_int(p, z); *p++ = '\t';

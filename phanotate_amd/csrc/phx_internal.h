@@ -33,6 +33,7 @@
 #define LINK_NONE 0u
 #define LINK_START (1u << 30) // payload = ORF index (contig-relative)
 #define LINK_STOP (2u << 30)  // payload = group index (contig-relative)
+#define LINK_TRNA (3u << 30)  // payload = index of the tRNA node (contig-relative, DBatch.tnode)
 #define LINK_IDX(x) ((x)&0x3fffffffu)
 #define LINK_KIND(x) ((x)&0xc0000000u)
 
@@ -76,6 +77,17 @@ struct DBridge {
     int32_t last, base;
 };
 
+// tRNA masking (functions.py:497-509): the nodes and edges add_trnas inserts, prepared on the host by phx_set_trnas
+struct DTNode {
+    int32_t pos;   // Node.position
+    int32_t info;  // NINFO(type, +-4)
+    int32_t other; // other_end['t' + str(pos)] as get_graph sees it (last writer wins)
+    int32_t rank;  // insertion rank among the tRNA nodes (they follow every CDS node, functions.py:357)
+};
+struct DTEdge {
+    int32_t src, dst; // tRNA node indices (contig-relative); weight -20 (functions.py:509)
+};
+
 struct DMeta { // one per contig
     int64_t off; // position offset into per-position arrays
     int32_t L;
@@ -115,6 +127,8 @@ struct DMeta { // one per contig
     int32_t dense;     // some node has more than ~62 close / open nodes within the next 500 bp: k_sssp_wave's windows cannot take it (k_edges<false>)
     double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
     int64_t win_off;   // first window record of this contig in DBatch.win (capacity n_node/16 + 7)
+    int32_t n_tnode, n_tedge; // tRNA nodes / edges of this contig (phx_set_trnas; layout, set on the host)
+    int64_t tn_off, te_off;
     int32_t tie;       // k_inorder: 0 the shortest path is unique, 1 equal-length alternatives exist and the solver's path is the in-order one,
                        // 2 the path was replaced by the in-order one, -1 not resolved (cannot happen)
     int32_t pad0;
@@ -185,6 +199,10 @@ struct DBatch {
     uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); zeroed every run
     uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
+    const DTNode *tnode; // tRNA nodes / edges of the batch (null: none)
+    const DTEdge *tedge;
+    int32_t *tnid;      // per tRNA node: its device node id (k_node_build -> k_edges)
+    uint64_t *tbits;    // per contig 12*nw words at 4/3 * nbits_off: node bitmaps of the tRNA nodes, planes (strand, type) = forward start, forward stop, reverse start, reverse stop; zeroed every run
     DBridge *bridge;    // per contig bridge_cap entries: the uncovered runs of functions.py:334 (k_node_rank -> k_edges)
     // per ORF / group
     DOrf *orf;

@@ -110,7 +110,7 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     by_stop = {}
     for k, r in enumerate(orf):
         by_stop.setdefault(int(r["stop"]), {})[int(r["start"])] = k
-    other_end = {int(n["pos"]): int(n["other"]) for n in nd if n["type"] < 2}
+    other_end = {int(n["pos"]): int(n["other"]) for n in nd if n["type"] < 2 and abs(int(n["frame"])) != 4}
 
     def o_term(p):  # functions.py:373-384
         if p in by_stop and other_end[p] in by_stop[p]:
@@ -125,7 +125,8 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     def rep(v):
         n = nd[v]
         t = TNAME[int(n["type"])]
-        return "Node(%r,%r,%r,%r)" % ("CDS" if n["type"] < 2 else t, t, int(n["frame"]), int(n["pos"]))
+        gene = t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS")
+        return "Node(%r,%r,%r,%r)" % (gene, t, int(n["frame"]), int(n["pos"]))
 
     ref = nd["refidx"]
     keyed = []
@@ -134,7 +135,10 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
         ts, td = int(nd[s]["type"]), int(nd[d]["type"])
         fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
         ps, pd = int(nd[s]["pos"]), int(nd[d]["pos"])
-        if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
+        if ts < 2 and td < 2 and fs == fd and abs(fs) == 4 and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
+            w = -Decimal(20)  # the tRNA edge, functions.py:509; add_trnas runs between the bridges and the connect loop
+            k = (1.5, int(ref[d]), 0)
+        elif ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
             # ORF edge start -> stop / stop -> start (functions.py:311-318)
             start, stop = (ps, pd) if fs > 0 else (pd, ps)
             w = oweight[by_stop[stop][start]]
@@ -146,7 +150,7 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
             w = _gap(L - ps, False, pgap)
             k = (3, int(ref[d]), 0)
         else:
-            diff = fs * fd < 0
+            diff = fs * fd < 0 and abs(fs) != 4 and abs(fd) != 4  # a pair with a tRNA node is scored 'same' on both strand combinations (functions.py:388-399)
             if ps < pd:  # left -> right: a gap edge of the connect loop, or a bridge over a non-coding run (same formula)
                 w = _gap(pd - ps - 3, diff, pgap)
                 l, r = s, d

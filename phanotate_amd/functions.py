@@ -62,7 +62,12 @@ class Orfs(OrderedDict):
 def get_orfs(locus):
     ann = _annotator(locus)
     seq = locus.seq()
-    (status, genes), = ann.annotate([seq])
+    # tRNA masking belongs to get_graph in the reference (functions.py:357); the GPU builds ORFs and graph in one pass, so
+    # the finders run here (phanotate_amd.trna does what functions.py:457-495 does, including the warning)
+    from .trna import find_trnas
+
+    hits = find_trnas(seq)
+    (status, genes), = ann.annotate([seq], trnas=None if hits is None else [hits])
     if status == -2:
         raise KeyError("letter outside the nucleotide alphabet")  # rev_comp, functions.py:20-24
     if status == -3:
@@ -79,7 +84,8 @@ def get_orfs(locus):
     for rec in ann.orfs(0):
         orfs.setdefault(int(rec["stop"]), OrderedDict())[int(rec["start"])] = Orf(rec, ann.params)
     nd = ann.nodes(0)
-    orfs.other_end = {int(n["pos"]): int(n["other"]) for n in nd if n["type"] < 2}
+    orfs.other_end = {int(n["pos"]): int(n["other"]) for n in nd if n["type"] < 2 and abs(int(n["frame"])) != 4}
+    orfs.other_end.update({"t" + str(int(n["pos"])): int(n["other"]) for n in nd if n["type"] < 2 and abs(int(n["frame"])) == 4})  # functions.py:502-508
     orfs._ann, orfs._genes, orfs._status = ann, genes, status
     return orfs
 
@@ -142,7 +148,7 @@ def get_graph(my_orfs):
     for v in order:
         n = nd[v]
         t = tname[int(n["type"])]
-        node = Node("CDS" if n["type"] < 2 else t, t, int(n["frame"]), int(n["pos"]))
+        node = Node(t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS"), t, int(n["frame"]), int(n["pos"]))
         nodes[repr(node)] = node
         G[node] = OrderedDict()
     buf = io.StringIO()

@@ -3,6 +3,8 @@
 excerpts pinned in the reference README (README.md:45-54, 60-61, 67-68) — the full writers live in the
 external `genbank` package, which is absent."""
 
+import numpy as np
+
 _COMP = str.maketrans("acgtrykmbvdhswnACGTRYKMBVDHSWN", "tgcayrmkvbhdswnTGCAYRMKVBHDSWN")
 _CODON = {}
 for _i, _a in enumerate("tcag"):
@@ -31,6 +33,8 @@ def write_tabular(out, name, genes):
     out.write("#id:\t" + name + "\n")
     out.write("#START\tSTOP\tFRAME\tCONTIG\tSCORE\n")
     for g in genes:
+        if abs(int(g["frame"])) == 4:  # a tRNA feature (functions.py:497-509): features(include=['CDS']) leaves it out (locus.py:42)
+            continue
         left, right = int(g["left"]), int(g["right"])
         if g["strand"] < 0:
             left, right = right, left  # locus.py:44-46
@@ -46,7 +50,7 @@ def write_genbank(out, name, seq, genes):
     out.write("LOCUS       %s %s bp \n" % (name.ljust(20), str(len(seq)).rjust(7)))
     out.write("FEATURES             Location/Qualifiers\n")
     for g in genes:
-        out.write("     CDS             %s\n" % _location(g))
+        out.write("     %s%s\n" % (("tRNA" if abs(int(g["frame"])) == 4 else "CDS").ljust(16), _location(g)))
         out.write("                     /note=score:%s\n" % score_text(g["score"]))
     out.write("ORIGIN\n")
     s = seq.lower()
@@ -56,19 +60,19 @@ def write_genbank(out, name, seq, genes):
 
 
 def write_fna(out, name, seq, genes):
-    for g in genes:
+    for g in genes[np.abs(genes["frame"]) != 4] if len(genes) else genes:
         out.write(">%s_CDS_[%s] [note=score:%s]\n%s\n" % (name, _location(g), score_text(g["score"]), gene_seq(seq, g)))
 
 
 def write_faa(out, name, seq, genes):
-    for g in genes:
+    for g in genes[np.abs(genes["frame"]) != 4] if len(genes) else genes:
         out.write(">%s_CDS_[%s] [note=score:%s]\n%s\n" % (name, _location(g), score_text(g["score"]), translate(gene_seq(seq, g))))
 
 
 def write_gff(out, name, seq, genes):
     out.write("##gff-version 3\n##sequence-region %s 1 %d\n" % (name, len(seq)))
     for g in genes:
-        out.write("%s\tPHANOTATE\tCDS\t%d\t%d\t%s\t%s\t0\tnote=score:%s\n" % (name, g["left"], g["right"], score_text(g["score"]), chr(44 - int(g["strand"])), score_text(g["score"])))
+        out.write("%s\tPHANOTATE\t" % name + ("tRNA" if abs(int(g["frame"])) == 4 else "CDS") + "\t%d\t%d\t%s\t%s\t0\tnote=score:%s\n" % (g["left"], g["right"], score_text(g["score"]), chr(44 - int(g["strand"])), score_text(g["score"])))
 
 
 FORMATS = ["tabular", "genbank", "fasta", "fna", "faa", "gff", "gff3"]

@@ -31,6 +31,13 @@ def load_golden(case):
     return g, name, seq
 
 
+def golden_trnas(g):
+    """The tRNA hit list of a fixture as functions.add_trnas holds it ([(start, stop)], reversed for complement hits), or None."""
+    if "trna_start" not in g:
+        return None
+    return list(zip(g["trna_start"].tolist(), g["trna_stop"].tolist()))
+
+
 def golden_params(g):
     """(start_codons, stop_codons, minlen) strings as the CLI would take them."""
     return dict(start_codons=str(g["params_start"]), stop_codons=str(g["params_stop"]), minlen=int(g["params_minlen"]))

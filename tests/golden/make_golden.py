@@ -134,14 +134,47 @@ def bellman_ford(nodes, edges, src, dst):
 TYPE_CODE = {"start": 0, "stop": 1, "source": 2, "target": 3}
 
 
-def make_case(case, name, seq, outdir, **params):
+FAKE_ARAGORN = """#!/bin/sh
+# stand-in for `aragorn -t -w <fasta>` while the fixtures are generated: prints the hit list of the case (batch format, -w)
+printf '%s' "$PHX_FAKE_ARAGORN_OUT"
+"""
+
+
+def aragorn_text(trnas):
+    """`aragorn -t -w` output for the hits [(begin, end, complement)]: what functions.add_trnas parses (functions.py:470-480)."""
+    lines = [">temp", "%d genes found" % len(trnas)]
+    for k, (a, b, c) in enumerate(trnas):
+        lines.append("%-3d tRNA-Xxx %20s[%d,%d]      35      (nnn)" % (k + 1, "c" if c else "", a, b))
+    return "\n".join(lines) + "\n"
+
+
+def make_case(case, name, seq, outdir, trnas=None, **params):
     locus = StubLocus(seq, **params)
     out = {"name": name, "L": len(seq)}
+    if trnas is not None:  # a fake `aragorn` on PATH (tRNAscan-SE stays absent): functions.py:457-509 runs as upstream would
+        import tempfile
+
+        td = tempfile.mkdtemp()
+        exe = os.path.join(td, "aragorn")
+        with open(exe, "w") as f:
+            f.write(FAKE_ARAGORN)
+        os.chmod(exe, 0o755)
+        os.environ["PATH"] = td + os.pathsep + os.environ["PATH"]
+        os.environ["PHX_FAKE_ARAGORN_OUT"] = aragorn_text(trnas)
+        # the list add_trnas builds: [begin, end], reversed for a complement hit
+        out["trna_start"] = np.array([b if c else a for a, b, c in trnas], dtype=np.int32)
+        out["trna_stop"] = np.array([a if c else b for a, b, c in trnas], dtype=np.int32)
+        out["aragorn_text"] = aragorn_text(trnas)
     out["params_start"] = ",".join("%s:%s" % (k, v) for k, v in locus.start_codons.items())
     out["params_stop"] = ",".join(locus.stop_codons)
     out["params_minlen"] = locus.min_orf_len
     try:
-        orfs, graph, cap, times = run_reference(locus)
+        try:
+            orfs, graph, cap, times = run_reference(locus)
+        finally:
+            if trnas is not None:
+                os.environ["PATH"] = os.pathsep.join(os.environ["PATH"].split(os.pathsep)[1:])
+                os.environ.pop("PHX_FAKE_ARAGORN_OUT")
     except Exception as e:  # reference aborts the run (SURVEY.md §5): record which way
         out["error"] = type(e).__name__
         np.savez_compressed(os.path.join(outdir, case + ".npz"), **{k: np.array(v) for k, v in out.items()})
@@ -168,12 +201,16 @@ def make_case(case, name, seq, outdir, **params):
     out["orf_log10_hold"] = np.array([float(D(o.hold).log10()) if o.hold != 0 else -np.inf for o in ol])
     out["orf_weight"] = np.array([float(o.weight) for o in ol])
     out["orf_weight_str"] = np.array([str(o.weight) for o in ol])
+    kt = sorted(int(k[1:]) for k in orfs.other_end if isinstance(k, str))  # 't'-prefixed keys of the tRNA nodes (functions.py:502-508)
+    out["other_end_tkey"] = np.array(kt, dtype=np.int32)
+    out["other_end_tval"] = np.array([orfs.other_end["t" + str(k)] for k in kt], dtype=np.int32)
     ks = sorted(k for k in orfs.other_end if isinstance(k, int))
     out["other_end_key"] = np.array(ks, dtype=np.int32)
     out["other_end_val"] = np.array([orfs.other_end[k] for k in ks], dtype=np.int32)
 
     nodes = list(graph.iternodes())
     nidx = {n: i for i, n in enumerate(nodes)}
+    out["node_gene"] = np.array([n.gene for n in nodes])
     out["node_type"] = np.array([TYPE_CODE[n.type] for n in nodes], dtype=np.int8)
     out["node_frame"] = np.array([n.frame for n in nodes], dtype=np.int8)
     out["node_pos"] = np.array([n.position for n in nodes], dtype=np.int32)
@@ -207,9 +244,10 @@ def make_case(case, name, seq, outdir, **params):
             w = graph.weight(Edge(left, right, 0))
             strand = -1 if left.frame < 0 else 1
             l, r = left.position, right.position + 2  # locus.py:30
-            genes.append((l, r, strand, float(w)))
+            genes.append((l, r, strand, float(w), left.frame))
             a_, b_ = (l, r) if strand > 0 else (r, l)  # locus.py:44-46
-            tab.write("%d\t%d\t%s\t%s\t%s\n" % (a_, b_, chr(44 - strand), name, "%E" % w))
+            if left.gene == "CDS":  # Locus.tabular prints features(include=['CDS']) only (locus.py:42)
+                tab.write("%d\t%d\t%s\t%s\t%s\n" % (a_, b_, chr(44 - strand), name, "%E" % w))
     else:
         out["edge_wint"] = np.array([], dtype="U1")
         out["path"] = np.array([], dtype=np.int32)
@@ -219,6 +257,7 @@ def make_case(case, name, seq, outdir, **params):
     out["gene_right"] = np.array([g[1] for g in genes], dtype=np.int32)
     out["gene_strand"] = np.array([g[2] for g in genes], dtype=np.int8)
     out["gene_score"] = np.array([g[3] for g in genes])
+    out["gene_frame"] = np.array([g[4] for g in genes], dtype=np.int8)
     out["tabular"] = tab.getvalue()
     np.savez_compressed(os.path.join(outdir, case + ".npz"), **{k: np.array(v) for k, v in out.items()})
     print(
@@ -280,6 +319,21 @@ def main():
     # non-default flags (file_handling.py:51-53)
     cases.append(("param_minlen60", "param_minlen60", synth(200, 6000), dict(minlen=60)))
     cases.append(("param_codons", "param_codons", synth(201, 6000), dict(start_codons="atg:0.7,gtg:0.2,ttg:0.05,ctg:0.05", stop_codons="tag,taa")))
+
+    # tRNA masking (functions.py:457-509, connect branch 388-399) through a fake `aragorn` on PATH: (begin, end, complement)
+    tr = {
+        # both strands; the first within 2000 bp of the left end, the last of the right end (source / target edges)
+        "trna_phiX174": ("phiX174", px, [(30, 104, False), (1200, 1275, False), (3000, 3080, True), (5290, 5370, True)]),
+        # two hits 25 bp apart; hits whose ends fall on positions of ORF nodes of both strands; one inside a long gene
+        "trna_lambda": ("NC_001416.1", lam, [(191, 265, False), (20000, 20075, False), (20100, 20180, False), (22686, 22760, True),
+                                             (25396, 25470, True), (35000, 35090, False), (35070, 35150, True), (46400, 46475, True)]),
+        "trna_synth6k": ("synth6k_100", synth(100, 6000), [(2500, 2572, True), (5800, 5890, False)]),
+        # hits inside a 900 bp ORF-free stretch (the bridge case): nothing competes there, so tRNA edges end up ON the path
+        "trna_gap": ("edge_bridge", lam[1000:4000] + gapseq + lam[4000:7000], [(3100, 3172, False), (3300, 3391, True), (3420, 3493, False), (3800, 3875, True)]),
+        "trna_gap_left": ("edge_bridge_left", gapseq + lam[4000:8000], [(40, 112, True), (300, 372, False), (301, 380, False), (700, 771, False)]),
+    }
+    for nm, (name, seq, hits) in tr.items():
+        cases.append((nm, name, seq, dict(trnas=hits)))
 
     for nm, name, seq, params in cases:
         if args.only and nm not in args.only:

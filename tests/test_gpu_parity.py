@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import exact_dist_from_device_edges, golden_cases, golden_params, inorder_bellman_ford, load_golden
+from conftest import exact_dist_from_device_edges, golden_cases, golden_params, golden_trnas, inorder_bellman_ford, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -92,8 +92,10 @@ def check_contig(ann, i, seq, o, genes, status, params=None):
     assert np.array_equal(nd["pos"][perm], o["node_pos"])
     assert np.array_equal(nd["type"][perm], o["node_type"])
     assert np.array_equal(nd["frame"][perm], o["node_frame"])
-    cds = nd["type"] < 2
+    trn = (nd["type"] < 2) & (np.abs(nd["frame"]) == 4)
+    cds = (nd["type"] < 2) & ~trn
     assert np.array_equal(nd["other"][cds], o["other_end"][nd["pos"][cds]])
+    assert np.array_equal(nd["other"][trn], o["other_end_t"][nd["pos"][trn]])  # other_end['t' + str(pos)], functions.py:502-508
     ed = ann.edges(i)
     assert len(ed) == len(o["edge_src"])
     if len(ed):
@@ -112,6 +114,7 @@ def check_contig(ann, i, seq, o, genes, status, params=None):
     assert np.array_equal(genes["left"], o["gene_left"])
     assert np.array_equal(genes["right"], o["gene_right"])
     assert np.array_equal(genes["strand"], o["gene_strand"].astype(np.int32))
+    assert np.array_equal(genes["frame"], o["gene_frame"].astype(np.int32))
     if len(genes):
         np.testing.assert_allclose(genes["score"], o["gene_score"], rtol=WTOL)
 
@@ -120,9 +123,10 @@ def check_contig(ann, i, seq, o, genes, status, params=None):
 def test_golden_case(case, pa, oracle):
     g, name, seq = load_golden(case)
     kw = golden_params(g)
+    tr = golden_trnas(g)
     ann = pa.Annotator(pa.make_params(**kw))
-    (status, genes), = ann.annotate([seq])
-    o = oracle.run(seq, oracle.make_params(**kw))
+    (status, genes), = ann.annotate([seq], trnas=None if tr is None else [tr])
+    o = oracle.run(seq, oracle.make_params(**kw), trnas=tr)
     if str(g["error"]):
         assert status < 0 and o["status"] < 0 and len(genes) == 0
     else:
@@ -131,8 +135,14 @@ def test_golden_case(case, pa, oracle):
         assert np.array_equal(genes["left"], g["gene_left"])
         assert np.array_equal(genes["right"], g["gene_right"])
         assert np.array_equal(genes["strand"], g["gene_strand"].astype(np.int32))
+        if "gene_frame" in g:
+            assert np.array_equal(genes["frame"], g["gene_frame"].astype(np.int32))  # +-4: a tRNA feature
         if len(genes):
             np.testing.assert_allclose(genes["score"], g["gene_score"], rtol=1e-6)
+        if tr is not None:
+            from phanotate_amd.cli import format_tabular
+
+            assert format_tabular([name], np.array([status], np.int32), np.array([0, len(genes)], np.int64), genes).decode() == str(g["tabular"])  # CDS features only
     ann.close()
 
 
@@ -155,6 +165,8 @@ def test_mixed_batch_equals_single_contig_runs(pa, oracle):
     items = []
     for c in golden_cases():
         g, name, seq = load_golden(c)
+        if golden_trnas(g) is not None:
+            continue
         if golden_params(g) == dict(start_codons=str(load_golden("phiX174")[0]["params_start"]), stop_codons="tag,tga,taa", minlen=90):
             items.append((c, seq))
     assert len(items) >= 20
@@ -780,8 +792,9 @@ def test_dump_text_is_byte_exact(case, pa):
     if str(g["error"]):
         pytest.skip("the reference raises on this input")
     kw = golden_params(g)
+    tr = golden_trnas(g)
     ann = pa.Annotator(pa.make_params(**kw))
-    (status, genes), = ann.annotate([seq])
+    (status, genes), = ann.annotate([seq], trnas=None if tr is None else [tr])
     assert status >= 0
     lines = dump_lines(ann, 0, seq, kw["start_codons"])
     assert len(lines) == len(g["edge_src"])
