@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--cli-contigs", type=int, default=1000, help="contigs of the end-to-end phanotate.py run (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-contig lines, the CPU baselines and the CLI run")
+    ap.add_argument("--smoke-single-device", action="store_true",
+                    help="N > 1 ranks on ONE GPU over gloo: exercises the sharded code path (partition, per-rank shards, flat gather) where no multi-GPU node is at hand; its numbers mean nothing")
     args = ap.parse_args()
 
     import numpy as np
@@ -182,13 +184,20 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py: no GPU visible; libphx has no CPU path\n")
         sys.exit(3)
+    if args.smoke_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cuda"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.smoke_single_device:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            red_dev = "cpu"
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     L_ = args.length
     if args.workload == "synthetic":
@@ -218,14 +227,14 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -286,7 +295,7 @@ def main():
             "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "u8/int128 (fp64 edge weights)",
-            "data": "synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)",
+            "data": ("synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)") + (" [SMOKE: all ranks on one GPU, gloo]" if args.smoke_single_device else ""),
             "value_is": "inputs resident in HBM when the timed region starts (task contract); host ASCII -> host gene lists is `host_to_host`",
             "config": {
                 "workload": wl,

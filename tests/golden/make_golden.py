@@ -330,6 +330,9 @@ def main():
         "trna_synth6k": ("synth6k_100", synth(100, 6000), [(2500, 2572, True), (5800, 5890, False)]),
         # hits inside a 900 bp ORF-free stretch (the bridge case): nothing competes there, so tRNA edges end up ON the path
         "trna_gap": ("edge_bridge", lam[1000:4000] + gapseq + lam[4000:7000], [(3100, 3172, False), (3300, 3391, True), (3420, 3493, False), (3800, 3875, True)]),
+        # the same hit twice: add_trnas adds the same edge again -> ValueError "parallel edges are forbidden" (graphs.py:74), the one
+        # abort of the reference that an input can reach (libphx: per-contig status PHX_S_PARALLEL, the batch goes on)
+        "trna_duplicate": ("synth6k_101", synth(101, 6000), [(2500, 2572, False), (4000, 4080, True), (2500, 2572, False)]),
         "trna_gap_left": ("edge_bridge_left", gapseq + lam[4000:8000], [(40, 112, True), (300, 372, False), (301, 380, False), (700, 771, False)]),
     }
     for nm, (name, seq, hits) in tr.items():

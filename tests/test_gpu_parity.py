@@ -129,6 +129,8 @@ def test_golden_case(case, pa, oracle):
     o = oracle.run(seq, oracle.make_params(**kw), trnas=tr)
     if str(g["error"]):
         assert status < 0 and o["status"] < 0 and len(genes) == 0
+        if str(g["error"]) == "ValueError":
+            assert status == -6 and o["status"] == -6  # "parallel edges are forbidden", graphs.py:74 (PHX_S_PARALLEL)
     else:
         check_contig(ann, 0, seq, o, genes, status, kw)
         # the reference's own numbers (Decimal + exact-integer solver), tests/golden/*.npz
@@ -803,3 +805,23 @@ def test_dump_text_is_byte_exact(case, pa):
         h.update((line + "\n").encode())
     assert h.hexdigest() == str(g["dump_md5"])
     ann.close()
+
+
+def test_bench_sharded_path_smoke():
+    """bench.py's N > 1 code path (config 5: shard.partition, per-rank shards, timed host-to-host region with the flat gather to
+    rank 0) with two ranks on this one GPU over gloo.  The numbers are meaningless; the line must come out and account for every contig."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--contigs", "120", "--length", "20000", "--smoke-single-device", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["contigs_total"] == 120 and d["config"]["contigs_rank0"] == 60
+    assert d["config"]["contigs_with_error_status"] == 0 and d["config"]["genes_called_total"] > 120 * 10
+    assert d["value"] > 0 and d["host_to_host"]["value"] > 0
