@@ -107,7 +107,8 @@ struct phx_ctx {
     // profiling
     bool prof = false;
     uint32_t prof_mask = 0xffffffffu; // stages that are bracketed by events when prof is on
-    bool force_global_sssp = false; // test hook: run every contig through the global-memory SSSP kernel
+    bool force_global_sssp = false; // development switch: run every contig through the global-memory SSSP kernel
+    bool no_wave = false, always_sync = false;
     float stage_ms[PHX_N_STAGES] = {0};
     int stage_n[PHX_N_STAGES] = {0};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -267,7 +268,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     k->win = std::min(cap_of(c->b_win, sizeof(DWin), 8), cap_of(c->b_wrole, sizeof(uint2) * WIN_ROLES, 8));
     k->edge = std::min(cap_of(c->b_esrc, 4, 1), cap_of(c->b_ew, 8, 1));
     k->limbs = limbs;
-    k->flags = (c->force_global_sssp ? 1 : 0) | (getenv("PHX_SSSP_NOWAVE") ? 2 : 0);
+    k->flags = (c->force_global_sssp ? 1 : 0) | (c->no_wave ? 2 : 0);
 }
 
 void fill_batch(phx_ctx *c, DBatch *b) {
@@ -420,8 +421,11 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     phx_ctx *c = new phx_ctx();
     c->device = device;
     c->params = *params;
-    c->force_global_sssp = getenv("PHX_FORCE_GLOBAL_SSSP") != nullptr; // test hook
+    // development switches, read once per context (tools/, not used by the tests): solver kernel selection, no HIP graph, sizing mode every run
+    c->force_global_sssp = getenv("PHX_FORCE_GLOBAL_SSSP") != nullptr;
+    c->no_wave = getenv("PHX_SSSP_NOWAVE") != nullptr;
     c->graphs_enabled = getenv("PHX_NO_GRAPH") == nullptr;
+    c->always_sync = getenv("PHX_ALWAYS_SYNC") != nullptr;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     if (flags & PHX_CREATE_USE_STREAM) { // as given; a null handle is HIP's null stream
@@ -864,17 +868,10 @@ int run_once(phx_ctx *c, bool learn) {
 
 } // namespace
 
-int phx_run(phx_ctx *c) {
-    if (!c) return PHX_E_ARG;
-    if (!c->uploaded) return PHX_E_STATE;
-    HIPCHK(c, hipSetDevice(c->device));
-    c->ran = false;
-    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
-    if (c->n == 0) { c->ran = true; return PHX_OK; }
-    int rc = run_once(c, !c->have_plan || getenv("PHX_ALWAYS_SYNC") != nullptr);
-    for (int attempt = 0; rc == kRetry && attempt < 3; attempt++) rc = run_once(c, true);
-    if (rc == kRetry) { c->err = "batch layout did not settle"; return PHX_E_STATE; }
-    if (rc) return rc;
+#ifdef PHX_DEV_REPORT
+// development builds only (make EXTRA="-DPHX_DEV_REPORT -DWV_PROFILE"): what the profiling variants of the solver kernels left in
+// the per-contig records, printed when PHX_DEBUG_WAVE / PHX_DEBUG_SSSP / PHX_DEBUG_CENSUS is set
+static void dev_report(phx_ctx *c) {
     const int n = c->n;
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_WAVE")) {
@@ -902,6 +899,23 @@ int phx_run(phx_ctx *c) {
                 c->meta[i].pmax[0] * 0.01, c->meta[i].pmax[1] * 0.01, c->meta[i].pmax[2] * 0.01, c->meta[i].pmax[3] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].pmin[1] * 0.01);
     if (getenv("PHX_DEBUG_SSSP"))
         for (int i = 0; i < n && i < 6; i++) fprintf(stderr, "sssp contig %d: V=%d iters=%d sweeps=%d setup=%.1fus iter=%.1fus tail=%.1fus\n", i, c->meta[i].n_node, c->meta[i].sssp_iters, c->meta[i].sweeps, c->meta[i].pmax[0] * 0.01, c->meta[i].pmin[0] * 0.01, c->meta[i].sssp_why * 0.01);
+}
+#endif
+
+int phx_run(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (!c->uploaded) return PHX_E_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->ran = false;
+    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
+    if (c->n == 0) { c->ran = true; return PHX_OK; }
+    int rc = run_once(c, !c->have_plan || c->always_sync);
+    for (int attempt = 0; rc == kRetry && attempt < 3; attempt++) rc = run_once(c, true);
+    if (rc == kRetry) { c->err = "batch layout did not settle"; return PHX_E_STATE; }
+    if (rc) return rc;
+#ifdef PHX_DEV_REPORT
+    dev_report(c); // per-contig timing of builds with -DWV_PROFILE / -DSW_PROFILE (tools/prof_wave.sh)
+#endif
     c->ran = true;
     return PHX_OK;
 }

@@ -240,7 +240,6 @@ void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *strea
 void phxk_orf_count(const DBatch *b, void *stream);
 void phxk_orf_emit(const DBatch *b, void *stream);
 void phxk_orf_stats(const DBatch *b, void *stream);
-void phxk_train(const DBatch *b, void *stream);
 void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);
 void phxk_node_attr(const DBatch *b, void *stream);

@@ -130,7 +130,6 @@ void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *strea
 void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b); }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, 6), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_train(const DBatch *, void *) {}
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
