@@ -145,7 +145,7 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 10), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
 // the overlap weights k_edges<true> left pending
 void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream) {
     if (b->defer_overlap && n_edges > 0)
