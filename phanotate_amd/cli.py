@@ -50,33 +50,18 @@ def dump_edges(out, ann, i, seq=None, start_codons="atg:0.85,gtg:0.10,ttg:0.05")
         for line in dump_lines(ann, i, seq, start_codons):
             out.write(line + "\n")
         return
+    from .dump import TNAME, edge_order
+
     nd = ann.nodes(i)
     ed = ann.edges(i)
-    tname = {0: "start", 1: "stop", 2: "source", 3: "target"}
 
     def rep(v):
         n = nd[v]
-        gene = "CDS" if n["type"] < 2 else tname[int(n["type"])]
-        return "Node(%r,%r,%r,%r)" % (gene, tname[int(n["type"])], int(n["frame"]), int(n["pos"]))
+        t = TNAME[int(n["type"])]
+        return "Node(%r,%r,%r,%r)" % (t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS"), t, int(n["frame"]), int(n["pos"]))
 
-    ref = nd["refidx"]
-    keyed = []
-    for e in ed:
-        s, d = int(e["src"]), int(e["dst"])
-        ts, td = int(nd[s]["type"]), int(nd[d]["type"])
-        orf_edge = ts < 2 and td < 2 and nd[s]["frame"] == nd[d]["frame"] and ((nd[s]["frame"] > 0 and ts == 0 and td == 1) or (nd[s]["frame"] < 0 and ts == 1 and td == 0))
-        if orf_edge:
-            k = (0, int(ref[d]), 0)
-        elif ts == 2 or td == 3:
-            k = (3, int(ref[d]), 0)
-        else:  # connector: the reference loops right node outer, left node inner (functions.py:360-366)
-            l, r = (s, d) if nd[s]["pos"] < nd[d]["pos"] else (d, s)
-            bridge = abs(int(nd[s]["pos"]) - int(nd[d]["pos"])) >= 500
-            k = (1 if bridge else 2, int(ref[r]), int(ref[l]))
-        keyed.append((int(ref[s]), k, s, d, float(e["w"])))
-    keyed.sort(key=lambda t: (t[0], t[1]))
-    for _, _, s, d, w in keyed:
-        out.write("%s\t%s\t%s\n" % (rep(s), rep(d), repr(w * 1000)))
+    for k in edge_order(nd, ed):
+        out.write("%s\t%s\t%s\n" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), repr(float(ed[k]["w"]) * 1000)))
 
 
 def format_tabular(names, status, offsets, genes):

@@ -92,6 +92,28 @@ def orf_weights(seq, orf, gcc, gl, weights, start_names):
     return pstops, out
 
 
+def edge_order(nd, ed):
+    """Indices of the tapped edges `ed` in Graph.iteredges order (graphs.py:121-126): by insertion rank of the source node, then
+    in the order get_graph adds a node's out-edges: its ORF edge(s) (functions.py:311-318), bridges (334-354), the tRNA edge
+    (509), the connect loop (360-438: right node outer, left node inner), source / target edges (440-452)."""
+    ref = nd["refidx"]
+    keys = []
+    for k, e in enumerate(ed):
+        s, d = int(e["src"]), int(e["dst"])
+        ts, td = int(nd[s]["type"]), int(nd[d]["type"])
+        fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
+        if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
+            cls = (1.5 if abs(fs) == 4 else 0, int(ref[d]), 0)
+        elif ts == 2 or td == 3:
+            cls = (3, int(ref[d]), 0)
+        else:
+            l, r = (s, d) if nd[s]["pos"] < nd[d]["pos"] else (d, s)
+            cls = (1 if abs(int(nd[s]["pos"]) - int(nd[d]["pos"])) >= 500 else 2, int(ref[r]), int(ref[l]))
+        keys.append((int(ref[s]), cls, k))
+    keys.sort()
+    return [k for _, _, k in keys]
+
+
 def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     """The --dump text of contig i of the batch `ann` last ran, as a list of lines (no newline)."""
     if isinstance(seq, (bytes, bytearray)):
@@ -128,37 +150,28 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
         gene = t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS")
         return "Node(%r,%r,%r,%r)" % (gene, t, int(n["frame"]), int(n["pos"]))
 
-    ref = nd["refidx"]
-    keyed = []
+    weight = []
     for e in ed:
         s, d = int(e["src"]), int(e["dst"])
         ts, td = int(nd[s]["type"]), int(nd[d]["type"])
         fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
         ps, pd = int(nd[s]["pos"]), int(nd[d]["pos"])
         if ts < 2 and td < 2 and fs == fd and abs(fs) == 4 and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
-            w = -Decimal(20)  # the tRNA edge, functions.py:509; add_trnas runs between the bridges and the connect loop
-            k = (1.5, int(ref[d]), 0)
+            w = -Decimal(20)  # the tRNA edge, functions.py:509
         elif ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
             # ORF edge start -> stop / stop -> start (functions.py:311-318)
             start, stop = (ps, pd) if fs > 0 else (pd, ps)
             w = oweight[by_stop[stop][start]]
-            k = (0, int(ref[d]), 0)
         elif ts == 2:  # functions.py:445-448
             w = _gap(pd, False, pgap)
-            k = (3, int(ref[d]), 0)
         elif td == 3:  # functions.py:449-452
             w = _gap(L - ps, False, pgap)
-            k = (3, int(ref[d]), 0)
         else:
             diff = fs * fd < 0 and abs(fs) != 4 and abs(fd) != 4  # a pair with a tRNA node is scored 'same' on both strand combinations (functions.py:388-399)
             if ps < pd:  # left -> right: a gap edge of the connect loop, or a bridge over a non-coding run (same formula)
                 w = _gap(pd - ps - 3, diff, pgap)
-                l, r = s, d
             else:  # right -> left: overlap edge, pstop = ave([o1, o2]) (functions.py:385)
-                l, r = d, s
-                pst = Decimal((o_term(int(nd[l]["pos"])) + o_term(int(nd[r]["pos"]))) / 2)
+                pst = Decimal((o_term(pd) + o_term(ps)) / 2)
                 w = _overlap(ps - pd + 3, diff, pst)
-            k = (1 if abs(ps - pd) >= 500 else 2, int(ref[r]), int(ref[l]))  # the loops run right node outer, left node inner
-        keyed.append((int(ref[s]), k, s, d, w))
-    keyed.sort(key=lambda t: (t[0], t[1]))
-    return ["%s\t%s\t%s" % (rep(s), rep(d), str(w * 1000)) for _, _, s, d, w in keyed]
+        weight.append(w)
+    return ["%s\t%s\t%s" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), str(weight[k] * 1000)) for k in edge_order(nd, ed)]

@@ -134,26 +134,24 @@ class Graph(OrderedDict):
 
 
 def get_graph(my_orfs):
-    """The graph libphx built for the contig of `my_orfs`, in the reference's insertion order."""
-    import io
-
-    from .cli import dump_edges
+    """The graph libphx built for the contig of `my_orfs`, in the reference's insertion order; the weights are the device's
+    fp64 values (phx_tap_edges), unchanged."""
+    from .dump import edge_order
 
     ann = my_orfs._ann
     nd = ann.nodes(0)
+    ed = ann.edges(0)
     tname = {0: "start", 1: "stop", 2: "source", 3: "target"}
     order = np.argsort(nd["refidx"], kind="stable")
-    nodes = {}
+    by_id = {}
     G = Graph()
     for v in order:
         n = nd[v]
         t = tname[int(n["type"])]
         node = Node(t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS"), t, int(n["frame"]), int(n["pos"]))
-        nodes[repr(node)] = node
+        by_id[int(v)] = node
         G[node] = OrderedDict()
-    buf = io.StringIO()
-    dump_edges(buf, ann, 0)
-    for line in buf.getvalue().splitlines():
-        s, d, w = line.split("\t")
-        G[nodes[s]][nodes[d]] = Edge(nodes[s], nodes[d], float(w) / 1000.0)
+    for k in edge_order(nd, ed):
+        s, d = int(ed[k]["src"]), int(ed[k]["dst"])
+        G[by_id[s]][by_id[d]] = Edge(by_id[s], by_id[d], float(ed[k]["w"]))
     return G

@@ -825,3 +825,36 @@ def test_bench_sharded_path_smoke():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["contigs_total"] == 120 and d["config"]["contigs_rank0"] == 60
     assert d["config"]["contigs_with_error_status"] == 0 and d["config"]["genes_called_total"] > 120 * 10
     assert d["value"] > 0 and d["host_to_host"]["value"] > 0
+
+
+def test_many_ambiguous_contigs_outgrow_the_tie_scratch(pa, oracle):
+    """k_inorder bump-allocates its scratch (36 B per node + 12 B per edge of a contig with equal-length alternatives) from a
+    buffer that starts at 1 MB: a batch full of such contigs overflows it, the run reports how much it wants and is repeated
+    with a larger buffer.  Every copy must come out like the first, and like the oracle."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+
+    rng = np.random.RandomState(101)
+    cands = [fuzz_gpu.make(rng) for _ in range(300)]
+    ann = pa.Annotator()
+    pick = None
+    for b0 in range(0, 300, 100):
+        res = ann.annotate(cands[b0 : b0 + 100])
+        for i, (st, genes) in enumerate(res):
+            if st == 0 and ann.globals(i).tie == 2 and ann.globals(i).n_node > 1500:
+                pick = cands[b0 + i]
+                break
+        if pick:
+            break
+    assert pick is not None, "no large ambiguous contig among the candidates"
+    o = oracle.run(pick)
+    fresh = pa.Annotator()  # a context whose scratch is still at its initial size
+    res = fresh.annotate([pick] * 96)
+    for i, (st, genes) in enumerate(res):
+        assert st == 0 and fresh.globals(i).tie == 2
+        assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]) and np.array_equal(genes["strand"], o["gene_strand"])
+    ann.close()
+    fresh.close()
