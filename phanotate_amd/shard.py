@@ -80,7 +80,7 @@ def run_sharded_flat(seqs, annotate_flat, rank=0, world=1, dist=None, mine=None)
         local = seqs
     st, offs, genes = annotate_flat(local)
     if world == 1:
-        return merge_flat([(idx, st, offs, genes)], n_total)
+        return st, offs, genes  # one rank holds every contig, already in input order
     gathered = [None] * world if rank == 0 else None
     dist.gather_object((idx, st, offs, genes), gathered, dst=0)
     if rank != 0:
