@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PHX_VERSION 100 /* 0.1.0 */
+#define PHX_VERSION 200 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew */
 #define PHX_MAX_CODONS 16
 
 /* library-level errors */

@@ -6,4 +6,4 @@ shared library has not been built, and phx_create fails without a HIP device.
 """
 from .api import Annotator, PhxError, make_params, synth_contig  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -77,7 +77,7 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_grp, b_bits, b_item;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_item;
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
@@ -255,7 +255,7 @@ int64_t cap_of(const DevBuf &b, size_t elem, int64_t reserve) {
 }
 void current_caps(const phx_ctx *c, DCaps *k) {
     const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
-    k->orf = cap_of(c->b_orf, sizeof(DOrf), 1);
+    k->orf = std::min(std::min(cap_of(c->b_orf, sizeof(DOrf), 1), cap_of(c->b_ostat, sizeof(DOrfStat), 1)), std::min(cap_of(c->b_oweight, 8, 1), cap_of(c->b_onode, 4, 1)));
     k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, 2 * sizeof(DGene), 1)); // a path k_inorder replaces may take new gene slots
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
     for (const DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist}) v = std::min(v, cap_of(*q, 4, 8));
@@ -287,6 +287,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->bridge = (DBridge *)c->b_bridge.p;
     if (c->has_trna) { b->tnode = (const DTNode *)c->b_tnode.p; b->tedge = (const DTEdge *)c->b_tedge.p; b->tnid = (int32_t *)c->b_tnid.p; b->tbits = (uint64_t *)c->b_tbits.p; }
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
+    b->ostat = (DOrfStat *)c->b_ostat.p; b->oweight = (double *)c->b_oweight.p; b->onode = (int32_t *)c->b_onode.p;
     b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
     b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
@@ -470,7 +471,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -669,6 +670,9 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         const size_t NV = (size_t)ht->node + 8, G = (size_t)ht->grp + 1;
         if ((rc = ensure(c, c->b_cbits, (size_t)(ht->cb + 8) * 8))) return rc;
         if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_ostat, sizeof(DOrfStat) * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_oweight, 8 * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_onode, 4 * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
         if ((rc = ensure(c, c->b_genes, 2 * sizeof(DGene) * G))) return rc;
         if ((rc = ensure(c, c->b_node, NV * sizeof(DNode)))) return rc;
@@ -1085,8 +1089,12 @@ int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
     if (m.status < 0 || m.n_orf == 0) return PHX_OK;
     if (!out) return PHX_E_ARG;
     std::vector<DOrf> d((size_t)m.n_orf);
+    std::vector<DOrfStat> ds((size_t)m.n_orf);
+    std::vector<double> dw((size_t)m.n_orf);
     std::vector<DGrp> grp((size_t)m.n_grp);
     HIPCHK(c, hipMemcpy(d.data(), (DOrf *)c->b_orf.p + m.orf_off, sizeof(DOrf) * d.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ds.data(), (DOrfStat *)c->b_ostat.p + m.orf_off, sizeof(DOrfStat) * ds.size(), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dw.data(), (double *)c->b_oweight.p + m.orf_off, 8 * dw.size(), hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(grp.data(), (DGrp *)c->b_grp.p + m.grp_off, sizeof(DGrp) * grp.size(), hipMemcpyDeviceToHost));
     std::vector<int> order, ref_rank, ref_first;
     reference_order(grp, order, ref_rank, ref_first);
@@ -1097,16 +1105,17 @@ int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
         const DGrp &G = grp[(size_t)order[rr]];
         for (int j = 0; j < G.n; j++, k++) {
             const DOrf &r = d[(size_t)(G.orf_begin + j)];
+            const DOrfStat &rs = ds[(size_t)(G.orf_begin + j)];
             phx_orf &o = out[k];
             o.start = r.start; o.stop = r.stop; o.frame = r.frame;
             o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
             o.rbs = r.rbs; o.startidx = r.startidx; o.group = (int32_t)rr;
             double S = 0;
-            for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = r.hist[a * 3 + cc]; S += (double)r.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
+            for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = rs.hist[a * 3 + cc]; S += (double)rs.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
             o.S = S;
-            o.pstop = r.pstop;
+            o.pstop = rs.pstop;
             o.weight_rbs = gl.training_rbs[r.rbs] / gl.background_rbs[r.rbs];
-            o.weight = r.weight;
+            o.weight = dw[(size_t)(G.orf_begin + j)];
         }
     }
     return PHX_OK;

@@ -3,7 +3,8 @@
 // Data layout in HBM (one batch = n contigs, concatenated):
 //   per position (index = meta.off + p, p 0-based):  ascii u8, cls u8, gcc u8, cnt u8, rbs u16,
 //       linkF u32, linkR u32, cov u8          (linkF/linkR/cov are indexed by 1-based position - 1)
-//   per ORF   (index = meta.orf_off + k, k in reference iter_orfs order):  DOrf (56 B)
+//   per ORF   (index = meta.orf_off + k):  DOrf head (16 B), DOrfStat (32 B), weight f64, start-node id i32 — four arrays, each
+//       written whole by one kernel (k_orf<true>, k_orf_stats, k_score, k_node_build)
 //   per group (index = meta.grp_off + g, g in reference insertion order):  DGrp (24 B)
 //   per node  (index = meta.node_off + v, v sorted by position; source = V-2, target = V-1):
 //       DNode {pos i32, info i32, link u32, other i32}, no f64, in_off u32 (+1), dist NL x u64, parent i32
@@ -50,18 +51,18 @@ struct DParams { // device copy of phx_params + derived tables
     uint8_t atg_tab[72];  // bit0: codon == 'atg', bit1: codon == 'cat'; entry 64 = 0
 };
 
-struct DOrf {
+struct DOrf { // what the scan knows about an ORF: one 16-byte store by k_orf<true>
     int32_t start, stop; // reference Orf.start / Orf.stop (1-based)
     int8_t frame;        // +-1..3
     uint8_t rbs;         // score_rbs bin
     int8_t startidx;     // index into params.start or -1
     uint8_t flags;       // bit0: Orf.start_codon() == 'atg'
     int32_t grp;         // contig-relative group index
-    int32_t node;        // device node id of the start node
+};
+struct DOrfStat { // its statistics: two 16-byte stores by k_orf_stats
     uint16_t hist[9];    // GC frame class histogram over the sense codons
-    uint16_t pad;
-    double pstop;
-    double weight;
+    uint16_t pad[3];
+    double pstop;        // Orf.p_stop, orfs.py:162-173
 };
 
 struct DGrp {
@@ -206,6 +207,9 @@ struct DBatch {
     DBridge *bridge;    // per contig bridge_cap entries: the uncovered runs of functions.py:334 (k_node_rank -> k_edges)
     // per ORF / group
     DOrf *orf;
+    DOrfStat *ostat;    // k_orf_stats -> k_score, k_node_attr
+    double *oweight;    // Orf.weight: k_score -> k_edges, genes
+    int32_t *onode;     // device node id of the ORF's start node: k_node_build -> k_edges
     DGrp *grp;
     // per node
     DNode *node;        // position, type/frame, link to its ORF / group, other_end: one 16-byte record per node
