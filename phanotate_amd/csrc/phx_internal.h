@@ -216,6 +216,7 @@ struct DBatch {
     int32_t *parent;
     uint32_t *in_off;
     double *no;
+    int32_t *npos;      // node positions alone (k_node_attr -> k_edges: its gap-edge loops need nothing else of a candidate, 4 instead of 16 bytes per look)
     DWin *win;          // k_wave_plan -> k_sssp_wave: window records,
     uint2 *wrole;       //   WIN_ROLES lane records per window
     int32_t *olist;     // per contig V-1 node ids: open nodes, the target, close nodes (k_node_order -> k_edges)
