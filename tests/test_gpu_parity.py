@@ -858,3 +858,64 @@ def test_many_ambiguous_contigs_outgrow_the_tie_scratch(pa, oracle):
         assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]) and np.array_equal(genes["strand"], o["gene_strand"])
     ann.close()
     fresh.close()
+
+
+def test_random_trna_hits_against_oracle(pa, oracle):
+    """tRNA masking beyond the fixtures: 160 fuzz contigs, each with 0-9 random hits on both strands (some within 2000 bp of an
+    end, clusters 10-200 bp apart, hits that share an end position, now and then the same hit twice = the reference's ValueError).
+    Status, gene list incl. the tRNA features and, for a sample, every stage tap must equal the oracle's."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+
+    rng = np.random.RandomState(4242)
+    seqs, hits = [], []
+    while len(seqs) < 160:
+        s = fuzz_gpu.make(rng).lower()
+        L = len(s)
+        if L < 400 or not set(s) <= set("acgtnryswkmbvdh"):
+            continue
+        h = []
+        p = int(rng.randint(1, L - 120))
+        for _ in range(int(rng.randint(0, 10))):
+            ln = int(rng.randint(60, 95))
+            kind = rng.randint(6)
+            if kind == 0:
+                p = int(rng.randint(1, L - 120))
+            elif kind == 1:
+                p = int(rng.randint(1, min(L - 120, 1900)))
+            elif kind == 2:
+                p = int(rng.randint(max(1, L - 1990), L - 120))
+            else:
+                p = min(L - 120, p + ln + int(rng.randint(-40, 200)))
+            p = max(1, p)
+            a, z = p, p + ln
+            h.append((z, a) if rng.rand() < 0.5 else (a, z))
+        if h and rng.rand() < 0.06:
+            h.append(h[int(rng.randint(len(h)))])  # the same hit twice
+        seqs.append(s)
+        hits.append(h)
+    ann = pa.Annotator()
+    n_on_path = n_dup = 0
+    for b0 in range(0, len(seqs), 40):
+        part, ph = seqs[b0 : b0 + 40], hits[b0 : b0 + 40]
+        res = ann.annotate(part, trnas=ph)
+        for i, (s, h, (status, genes)) in enumerate(zip(part, ph, res)):
+            o = oracle.run(s, trnas=h)
+            if o["status"] == -7:
+                continue
+            if o["status"] < 0:
+                assert status == o["status"], (b0 + i, status, o["status"])
+                n_dup += o["status"] == -6
+                continue
+            assert status == (1 if len(o["node_pos"]) > 2 and not len(o["path"]) else 0), (b0 + i)
+            assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]), (b0 + i)
+            assert np.array_equal(genes["frame"], o["gene_frame"].astype(np.int32)), (b0 + i)
+            n_on_path += int((np.abs(genes["frame"]) == 4).sum())
+            if i % 8 == 0 and status == 0:
+                check_contig(ann, i, s, o, genes, status)
+    assert n_on_path >= 20, "only %d tRNA features ended up on a path" % n_on_path
+    assert n_dup >= 1
+    ann.close()
