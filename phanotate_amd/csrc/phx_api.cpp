@@ -275,6 +275,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
 void fill_batch(phx_ctx *c, DBatch *b) {
     memset(b, 0, sizeof(*b));
     b->n_contig = c->n;
+    b->mean_len = c->n > 0 ? c->totalL / c->n : 0;
     b->meta = (DMeta *)c->b_meta.p;
     b->tot = (DTotals *)c->b_tot.p;
     current_caps(c, &b->caps);

@@ -186,6 +186,7 @@ struct DCaps {
 
 struct DBatch {
     int32_t n_contig;
+    int64_t mean_len;   // mean contig length of the batch (launch geometry of the per-contig kernels)
     DMeta *meta;
     DTotals *tot;
     DCaps caps;

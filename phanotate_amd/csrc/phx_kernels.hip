@@ -127,25 +127,34 @@ extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
     if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
 }
-void phxk_orf_count(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<false>, dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b); }
-void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, 6), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, 8), dim3(NT), 0, (hipStream_t)stream, *b); }
+// Workgroups per contig of the per-contig kernels: `full` for the benchmark's 50 kb contigs, fewer for batches of short contigs
+// (a 2 kb contig has ~100 nodes: four workgroups of 256 threads would leave three idle), by the batch's mean contig length.
+static unsigned ysplit(const DBatch *b, unsigned full) {
+    const unsigned y = (unsigned)((b->mean_len + 8191) / 8192);
+    return y < 1u ? 1u : (y > full ? full : y);
+}
+void phxk_orf_count(const DBatch *b, void *stream) {
+    if (b->mean_len < 16384) hipLaunchKernelGGL((k_orf<false, 256>), dim3(b->n_contig), dim3(256), 0, (hipStream_t)stream, *b);
+    else hipLaunchKernelGGL((k_orf<false, ORF_COUNT_T>), dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b);
+}
+void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, 6)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, 8)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
-    hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_order, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 // part 2: other_end and the p_stop attribute of every node (reads DOrf.pstop of k_orf_stats)
-void phxk_node_attr(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_node_attr(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_count(const DBatch *b, void *stream) {
-    hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, 4), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 // the overlap weights k_edges<true> left pending
 void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream) {
     if (b->defer_overlap && n_edges > 0)
