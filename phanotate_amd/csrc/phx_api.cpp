@@ -723,7 +723,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
     HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
-    phxk_wave_plan(&b, c->aux[3]);
+    phxk_wave_plan(&b, (mask >> 6) & 1, c->aux[3]); // bit 4*1+2: 256-bit contigs for the wavefront kernel
     HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
@@ -739,15 +739,19 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         int nlaunch = 0, nclass = 0;
         bool used[3] = {false, false, false};
         for (int k = 0; k < 4; k++) nclass += ((mask >> (4 * k)) & 7) ? 1 : 0;
-        // contigs of the 128-bit class that never enter the wavefront kernel (too dense for its windows) are solved by the
-        // workgroup kernel on a side stream, beside the wavefront kernel; the launch after the wavefront kernel then only
-        // takes what that kernel handed back
-        const bool early = ((mask >> 2) & 1) && ((mask >> 16) & 1) && c->aux[2];
+        // contigs that never enter the wavefront kernel (too dense for its windows: k_edges<false>; a window the planner could not
+        // lay out: k_wave_plan, which has finished by now) are solved by the workgroup kernel on a side stream, beside the
+        // wavefront kernel; the launch after the wavefront kernel then only takes what that kernel handed back while it ran
+        bool early = false;
+        auto early_k = [&](int k) { return ((mask >> (4 * k + 2)) & 1) && ((mask >> (4 * k + 1)) & 1) && (((mask >> (16 + k)) | (mask >> (20 + k))) & 1); }; // such contigs existed in the run this one is modelled on
+        for (int k = 0; k < 4; k++) early = early || early_k(k);
+        early = early && c->aux[2];
         if ((nclass > 1 || early) && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
         if (early) {
             HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork, 0));
             used[2] = true;
-            phxk_sssp(&b, 2, 1, (size_t)lds[0], c->aux[2]);
+            for (int k = 3; k >= 0; k--)
+                if (early_k(k)) phxk_sssp(&b, nl_of[k], 1, (size_t)lds[k], c->aux[2]);
             HIPCHK(c, hipEventRecord(c->ev_join[2], c->aux[2]));
         }
         for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
@@ -760,7 +764,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
             }
             for (int mode = 2; mode >= 0; mode--)
                 if ((mask >> (4 * k + mode)) & 1) {
-                    if (early && k == 0 && mode == 1) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launch: it skips what that one solved
+                    if (early && mode == 1 && early_k(k)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launch: it skips what that one solved
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                 }
             nlaunch++;
@@ -861,7 +865,7 @@ int run_once(phx_ctx *c, bool learn) {
     const DTotals *ht = c->h_tot;
     c->tie_seen = std::max(c->tie_seen, ht->tie_need);
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
-    bool covered = (ht->class_mask & ~mask) == 0;
+    bool covered = ((ht->class_mask & ~mask) & 0xffff) == 0; // (bits 16+: which classes have contigs for the side launch of the workgroup kernel: a matter of speed only)
     for (int k = 0; k < 4; k++) covered = covered && ht->lds_need[k] <= lds[k];
     if (ht->class_mask != c->last_mask || ht->lds_need[0] != c->last_lds[0] || ht->lds_need[1] != c->last_lds[1] || ht->lds_need[2] != c->last_lds[2] || ht->lds_need[3] != c->last_lds[3])
         c->graph_valid = false; // the next run launches other solver kernels / LDS sizes

@@ -255,7 +255,7 @@ void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge off
 void phxk_edges_fill(const DBatch *b, void *stream);
 void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
-void phxk_wave_plan(const DBatch *b, void *stream);
+void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them

@@ -919,3 +919,31 @@ def test_random_trna_hits_against_oracle(pa, oracle):
     assert n_on_path >= 20, "only %d tRNA features ended up on a path" % n_on_path
     assert n_dup >= 1
     ann.close()
+
+
+@pytest.mark.parametrize("ncodons", [2200, 3000, 3800])
+def test_256_bit_contigs_on_the_wavefront_kernel(pa, oracle, ncodons):
+    """A 6.6-11 kb stop-free reading frame in an otherwise ordinary 40 kb contig: the path sums need more than 128 bits (a
+    phage tail-fibre-sized gene is enough).  Such contigs are solved by k_sssp_wave<4> (the same wavefront kernel on 256-bit
+    distances) instead of dropping to the workgroup kernel: distances exact, genes = the exact solution of the oracle's graph."""
+    rng = np.random.RandomState(ncodons)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    seqs = []
+    for k in range(6):
+        body = "".join(rng.choice(sense, ncodons))
+        seqs.append(pa.synth_contig(900 + k, 20000).decode() + "atg" + body + "taa" + pa.synth_contig(1900 + k, 20000).decode())
+    ann = pa.Annotator()
+    res = ann.annotate(seqs)
+    n4 = 0
+    for i, (s, (status, genes)) in enumerate(zip(seqs, res)):
+        gl = ann.globals(i)
+        assert status == 0
+        if gl.n_limbs == 4:
+            n4 += 1
+            assert gl.sssp_kernel == 2 and gl.sssp_handed_back == 0, (i, gl.sssp_kernel, gl.sssp_handed_back)
+        o = oracle.run(s, stages=2)
+        dist, want = _py_bellman_ford_genes(o)
+        assert [(int(g["left"]), int(g["right"])) for g in genes] == want, i
+        check_exact_distances(ann, i)
+    assert n4 >= 1, "no contig of this batch needed 256 bits"
+    ann.close()
