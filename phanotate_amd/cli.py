@@ -100,6 +100,21 @@ def main(argv=None):
 
     t_start = time.perf_counter()
     args = get_args(argv)
+    device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    # the HIP runtime and the context come up (~0.2 s) on a worker thread while this one reads the FASTA file
+    import threading
+
+    ctx_box = {}
+
+    def make_context():
+        try:
+            ctx_box["ann"] = Annotator(make_params(args.start_codons, args.stop_codons, args.min_orf_len), device=device)
+        except BaseException as e:  # re-raised on the main thread
+            ctx_box["err"] = e
+
+    ctx_thread = threading.Thread(target=make_context, daemon=True)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:  # (sharded runs bring torch.distributed up first, on this thread)
+        ctx_thread.start()
     fa = Fasta(args.infile)
     if not len(fa) or not int(fa.lens.sum()):
         sys.stdout.write("Error: no sequences found in infile\n")  # phanotate.py:33-35
@@ -107,7 +122,6 @@ def main(argv=None):
     t_parsed = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch
@@ -115,8 +129,15 @@ def main(argv=None):
 
         torch.cuda.set_device(device)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    params = make_params(args.start_codons, args.stop_codons, args.min_orf_len)
-    ann = Annotator(params, device=device)
+    if world == 1:
+        ctx_thread.join()
+    else:
+        make_context()
+    if "err" in ctx_box:
+        raise ctx_box["err"]
+    ann = ctx_box["ann"]
+    t_ctx = time.perf_counter()
+    t_parts = {"upload_s": 0.0, "run_s": 0.0, "download_s": 0.0, "batches": 0}
     import shutil
 
     from .trna import find_trnas
@@ -148,10 +169,15 @@ def main(argv=None):
             while hi < len(idx) and (hi == lo or size + int(fa.lens[idx[hi]]) <= args.batch_bases):
                 size += int(fa.lens[idx[hi]])
                 hi += 1
+            t0 = time.perf_counter()
             ann.upload_raw(fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa)
             ann.set_trnas(trnas_of(idx[lo:hi]))
+            t1 = time.perf_counter()
             ann.run()
+            t2 = time.perf_counter()
             parts.append(ann.download_flat())
+            t3 = time.perf_counter()
+            t_parts["upload_s"] += t1 - t0; t_parts["run_s"] += t2 - t1; t_parts["download_s"] += t3 - t2; t_parts["batches"] += 1
             lo = hi
             if lo >= len(idx):
                 break
@@ -188,7 +214,8 @@ def main(argv=None):
     t_end = time.perf_counter()
     if os.environ.get("PHX_CLI_TIMING") and rank == 0:
         sys.stderr.write("PHX_CLI_TIMING " + json.dumps({"parse_s": round(t_parsed - t_start, 4), "gpu_s": round(t_gpu - t_parsed, 4), "format_s": round(t_fmt - t_gpu, 4),
-                                                         "write_s": round(t_end - t_fmt, 4), "total_s": round(t_end - t_start, 4), "bases": int(fa.lens.sum()), "genes": int(len(merged[2]))}) + "\n")
+                                                         "write_s": round(t_end - t_fmt, 4), "total_s": round(t_end - t_start, 4), "bases": int(fa.lens.sum()), "genes": int(len(merged[2])),
+                                                         "gpu_parts": dict({k: round(v, 4) for k, v in t_parts.items()}, context_s=round(t_ctx - t_parsed, 4))}) + "\n")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -5,17 +5,22 @@
  * phanotate.py:32-35: every record's name = first token of the header, README.md:45) and the tabular writer
  * phanotate_modules/locus.py:39-56.
  */
+#define _POSIX_C_SOURCE 200809L
 #include <ctype.h>
+#include <fcntl.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include "../../include/phx.h"
 
 struct phx_fasta {
-    char *buf;        /* the file, compacted in place: the sequences back to back */
+    char *buf;        /* the sequences back to back */
     char *names;      /* NUL-terminated names back to back */
     int64_t *seq_off; /* n + 1 */
     int64_t *name_off;
@@ -24,16 +29,50 @@ struct phx_fasta {
 
 static int is_space(int c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\v' || c == '\f'; }
 
-/* whole file (plain or gzip: zlib reads both) into one buffer */
+/* worker threads of the host utilities: PHX_HOST_THREADS, else the online cores, at most 16 */
+static int host_threads(void) {
+    const char *e = getenv("PHX_HOST_THREADS");
+    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    return n < 1 ? 1 : (n > 16 ? 16 : (int)n);
+}
+/* run fn(arg + i * stride) for i < n on n threads (the calling thread takes the last one; a thread that cannot be created runs inline) */
+static void run_threads(void *(*fn)(void *), void *arg, size_t stride, int n) {
+    pthread_t th[16];
+    int made[16];
+    for (int i = 0; i + 1 < n; i++) made[i] = pthread_create(&th[i], NULL, fn, (char *)arg + (size_t)i * stride) == 0;
+    fn((char *)arg + (size_t)(n - 1) * stride);
+    for (int i = 0; i + 1 < n; i++) { if (made[i]) pthread_join(th[i], NULL); else fn((char *)arg + (size_t)i * stride); }
+}
+
+/* whole file into one buffer: a plain file with read(), a gzip file (magic 1f 8b) through zlib */
 static int slurp(const char *path, char **out, int64_t *len) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return PHX_E_IO;
+    unsigned char magic[2] = {0, 0};
+    struct stat st;
+    const ssize_t got2 = read(fd, magic, 2);
+    if (got2 == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+        const int64_t size = (int64_t)st.st_size;
+        char *b = (char *)malloc((size_t)size + 16);
+        if (!b) { close(fd); return PHX_E_NOMEM; }
+        b[0] = (char)magic[0]; b[1] = (char)magic[1];
+        int64_t n = 2;
+        while (n < size) {
+            const int64_t want = size - n > (1 << 30) ? (1 << 30) : size - n;
+            const ssize_t got = read(fd, b + n, (size_t)want);
+            if (got < 0) { free(b); close(fd); return PHX_E_IO; }
+            if (got == 0) break;
+            n += got;
+        }
+        close(fd);
+        *out = b; *len = n;
+        return PHX_OK;
+    }
+    close(fd);
     gzFile g = gzopen(path, "rb");
     if (!g) return PHX_E_IO;
     gzbuffer(g, 1 << 20);
     int64_t cap = 1 << 22, n = 0;
-    if (gzdirect(g)) { /* not compressed: size the buffer from the file */
-        FILE *f = fopen(path, "rb");
-        if (f) { if (fseek(f, 0, SEEK_END) == 0) { long s = ftell(f); if (s > 0) cap = (int64_t)s + 16; } fclose(f); }
-    }
     char *b = (char *)malloc((size_t)cap);
     if (!b) { gzclose(g); return PHX_E_NOMEM; }
     for (;;) {
@@ -54,6 +93,55 @@ static int slurp(const char *path, char **out, int64_t *len) {
     return PHX_OK;
 }
 
+/* The file is cut into one segment per thread at line starts.  Pass 1 sizes every segment (records, name bytes, sequence bytes in
+ * front of / behind its first header), a prefix sum places them, pass 2 copies names and stripped sequence lines to their places. */
+typedef struct {
+    const char *b;
+    int64_t p0, p1;               /* segment [p0, p1): whole lines */
+    int64_t nrec, name_bytes, pre, post;
+    int64_t rec0, name0, seq0;    /* first record index, name offset, sequence write offset of this segment */
+    int have_prev;                /* a record starts before this segment: its leading sequence lines belong to it */
+    phx_fasta *f;
+    char *dst;
+    int pass;
+} fa_seg;
+
+static void *fa_work(void *arg) {
+    fa_seg *g = (fa_seg *)arg;
+    const char *b = g->b;
+    int64_t nrec = 0, nb = 0, pre = 0, post = 0;
+    int64_t k = g->rec0 - 1, nw = g->name0, w = g->seq0;
+    phx_fasta *f = g->f;
+    for (int64_t p = g->p0; p < g->p1;) {
+        const char *nl = (const char *)memchr(b + p, '\n', (size_t)(g->p1 - p));
+        const int64_t e = nl ? nl - b : g->p1;
+        if (b[p] == '>') {
+            int64_t a = p + 1;
+            while (a < e && is_space((unsigned char)b[a])) a++; /* line[1:].split()[0] */
+            int64_t z = a;
+            while (z < e && !is_space((unsigned char)b[z])) z++;
+            if (g->pass == 1) { nrec++; nb += z - a + 1; }
+            else {
+                k++;
+                f->seq_off[k] = w;
+                f->name_off[k] = nw;
+                memcpy(f->names + nw, b + a, (size_t)(z - a));
+                nw += z - a;
+                f->names[nw++] = 0;
+            }
+        } else {
+            int64_t a = p, z = e;
+            while (a < z && is_space((unsigned char)b[a])) a++;
+            while (z > a && is_space((unsigned char)b[z - 1])) z--;
+            if (g->pass == 1) { if (nrec) post += z - a; else pre += z - a; }
+            else if (k >= 0 && z > a) { memcpy(g->dst + w, b + a, (size_t)(z - a)); w += z - a; } /* text before the first header is ignored */
+        }
+        p = e + 1;
+    }
+    if (g->pass == 1) { g->nrec = nrec; g->name_bytes = nb; g->pre = pre; g->post = post; }
+    return NULL;
+}
+
 int phx_fasta_read(const char *path, phx_fasta **out) {
     if (!path || !out) return PHX_E_ARG;
     *out = NULL;
@@ -61,49 +149,39 @@ int phx_fasta_read(const char *path, phx_fasta **out) {
     int64_t len = 0;
     int rc = slurp(path, &b, &len);
     if (rc) return rc;
-    /* pass 1: records and the room their names need */
-    int64_t nrec = 0, name_bytes = 0;
-    for (int64_t p = 0; p < len;) {
-        const char *nl = (const char *)memchr(b + p, '\n', (size_t)(len - p));
-        const int64_t e = nl ? nl - b : len;
-        if (b[p] == '>') { nrec++; name_bytes += e - p; }
-        p = e + 1;
+    fa_seg seg[16];
+    int T = len < (4 << 20) ? 1 : host_threads();
+    int64_t cut = 0;
+    int ns = 0;
+    for (int i = 0; i < T && cut < len; i++) { /* segment ends: the first line start at or behind (i + 1) * len / T */
+        int64_t e = i + 1 == T ? len : (len / T) * (i + 1);
+        if (e < cut) e = cut;
+        if (e < len) { const char *nl = (const char *)memchr(b + e, '\n', (size_t)(len - e)); e = nl ? nl - b + 1 : len; }
+        memset(&seg[ns], 0, sizeof(seg[ns]));
+        seg[ns].b = b; seg[ns].p0 = cut; seg[ns].p1 = e; seg[ns].pass = 1;
+        cut = e;
+        ns++;
+    }
+    if (ns) run_threads(fa_work, seg, sizeof(fa_seg), ns);
+    int64_t nrec = 0, name_bytes = 0, seq_bytes = 0;
+    for (int i = 0; i < ns; i++) {
+        seg[i].rec0 = nrec; seg[i].name0 = name_bytes; seg[i].seq0 = seq_bytes; seg[i].have_prev = nrec > 0;
+        seq_bytes += (nrec > 0 ? seg[i].pre : 0) + seg[i].post;
+        nrec += seg[i].nrec; name_bytes += seg[i].name_bytes;
     }
     phx_fasta *f = (phx_fasta *)calloc(1, sizeof(*f));
     if (!f) { free(b); return PHX_E_NOMEM; }
-    f->buf = b;
+    f->buf = (char *)malloc((size_t)seq_bytes + 16);
     f->names = (char *)malloc((size_t)name_bytes + 1);
     f->seq_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
     f->name_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
-    if (!f->names || !f->seq_off || !f->name_off || nrec > 0x7fffffff) { phx_fasta_free(f); return PHX_E_NOMEM; }
-    /* pass 2: names out, sequence lines stripped and moved down (the write position never passes the read position) */
-    int64_t w = 0, nw = 0;
-    int32_t k = -1;
-    for (int64_t p = 0; p < len;) {
-        const char *nl = (const char *)memchr(b + p, '\n', (size_t)(len - p));
-        const int64_t e = nl ? nl - b : len;
-        if (b[p] == '>') {
-            k++;
-            f->seq_off[k] = w;
-            f->name_off[k] = nw;
-            int64_t a = p + 1;
-            while (a < e && is_space((unsigned char)b[a])) a++; /* line[1:].split()[0] */
-            int64_t z = a;
-            while (z < e && !is_space((unsigned char)b[z])) z++;
-            memcpy(f->names + nw, b + a, (size_t)(z - a));
-            nw += z - a;
-            f->names[nw++] = 0;
-        } else if (k >= 0) { /* text before the first header is ignored */
-            int64_t a = p, z = e;
-            while (a < z && is_space((unsigned char)b[a])) a++;
-            while (z > a && is_space((unsigned char)b[z - 1])) z--;
-            if (z > a) { memmove(b + w, b + a, (size_t)(z - a)); w += z - a; }
-        }
-        p = e + 1;
-    }
-    f->n = k + 1;
-    f->seq_off[f->n] = w;
-    f->name_off[f->n] = nw;
+    if (!f->buf || !f->names || !f->seq_off || !f->name_off || nrec > 0x7fffffff) { free(b); phx_fasta_free(f); return PHX_E_NOMEM; }
+    for (int i = 0; i < ns; i++) { seg[i].pass = 2; seg[i].f = f; seg[i].dst = f->buf; }
+    if (ns) run_threads(fa_work, seg, sizeof(fa_seg), ns);
+    free(b);
+    f->n = (int32_t)nrec;
+    f->seq_off[f->n] = seq_bytes;
+    f->name_off[f->n] = name_bytes;
     *out = f;
     return PHX_OK;
 }
@@ -145,39 +223,79 @@ static char *put_int(char *p, int32_t v) {
     return p;
 }
 
-int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *genes, const int64_t *offsets, const int32_t *status, char **text, int64_t *text_len) {
-    if (n < 0 || !text || !text_len || (n > 0 && (!names || !offsets || !status))) return PHX_E_ARG;
-    *text = NULL; *text_len = 0;
-    /* upper bound of the text: header lines + per gene two coordinates (11 each), strand, name, score (<= 24), separators */
-    int64_t need = 1;
-    for (int32_t i = 0; i < n; i++) {
-        if (status[i] < 0) continue;
-        const int64_t ln = (int64_t)strlen(names[i]);
-        need += 6 + ln + 1 + 34 + (offsets[i + 1] - offsets[i]) * (11 + 1 + 11 + 1 + 1 + 1 + ln + 1 + 24 + 1);
-    }
-    char *b = (char *)malloc((size_t)need);
-    if (!b) return PHX_E_NOMEM;
-    char *p = b;
-    for (int32_t i = 0; i < n; i++) {
-        if (status[i] < 0) continue;
-        const size_t ln = strlen(names[i]);
+typedef struct {
+    int32_t c0, c1;          /* contigs [c0, c1) */
+    const char *const *names;
+    const phx_gene *genes;
+    const int64_t *offsets;
+    const int32_t *status;
+    char *dst;               /* this thread's region of the text buffer */
+    int64_t len;             /* bytes written */
+} fmt_job;
+
+static void *fmt_work(void *arg) {
+    fmt_job *j = (fmt_job *)arg;
+    char *p = j->dst;
+    for (int32_t i = j->c0; i < j->c1; i++) {
+        if (j->status[i] < 0) continue;
+        const char *nm = j->names[i];
+        const size_t ln = strlen(nm);
         memcpy(p, "#id:\t", 5); p += 5;
-        memcpy(p, names[i], ln); p += ln;
+        memcpy(p, nm, ln); p += ln;
         *p++ = '\n';
         memcpy(p, "#START\tSTOP\tFRAME\tCONTIG\tSCORE\n", 31); p += 31;
-        for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
-            const phx_gene *g = &genes[k];
+        for (int64_t k = j->offsets[i]; k < j->offsets[i + 1]; k++) {
+            const phx_gene *g = &j->genes[k];
             if (g->frame == 4 || g->frame == -4) continue; /* a tRNA feature: Locus.tabular lists features(include=['CDS']), locus.py:42 */
             const int32_t a = g->strand < 0 ? g->right : g->left, z = g->strand < 0 ? g->left : g->right; /* locus.py:44-46 */
             p = put_int(p, a); *p++ = '\t';
             p = put_int(p, z); *p++ = '\t';
             *p++ = (char)(44 - g->strand); *p++ = '\t'; /* chr(44 - strand), locus.py:51 */
-            memcpy(p, names[i], ln); p += ln;
+            memcpy(p, nm, ln); p += ln;
             *p++ = '\t';
             p += snprintf(p, 25, "%E", g->score);
             *p++ = '\n';
         }
     }
+    j->len = p - j->dst;
+    return NULL;
+}
+
+int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *genes, const int64_t *offsets, const int32_t *status, char **text, int64_t *text_len) {
+    if (n < 0 || !text || !text_len || (n > 0 && (!names || !offsets || !status))) return PHX_E_ARG;
+    *text = NULL; *text_len = 0;
+    /* upper bound of the text: header lines + per gene two coordinates (11 each), strand, name, score (<= 24), separators */
+    int64_t *bound = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    if (!bound) return PHX_E_NOMEM;
+    int64_t need = 1;
+    for (int32_t i = 0; i < n; i++) {
+        bound[i] = need;
+        if (status[i] < 0) continue;
+        const int64_t ln = (int64_t)strlen(names[i]);
+        need += 6 + ln + 1 + 34 + (offsets[i + 1] - offsets[i]) * (11 + 1 + 11 + 1 + 1 + 1 + ln + 1 + 24 + 1);
+    }
+    bound[n] = need;
+    char *b = (char *)malloc((size_t)need);
+    if (!b) { free(bound); return PHX_E_NOMEM; }
+    /* contiguous contig ranges of about equal size, one per thread; every thread writes at its range's bound, then the pieces move together */
+    fmt_job job[16];
+    const int T = need < (1 << 20) ? 1 : host_threads();
+    int nj = 0;
+    int32_t c = 0;
+    for (int t = 0; t < T && c < n; t++) {
+        const int64_t target = t + 1 == T ? need : bound[0] + (need - bound[0]) / T * (t + 1);
+        int32_t e = c;
+        while (e < n && (bound[e + 1] <= target || e == c)) e++;
+        if (t + 1 == T) e = n;
+        job[nj].c0 = c; job[nj].c1 = e; job[nj].names = names; job[nj].genes = genes; job[nj].offsets = offsets; job[nj].status = status;
+        job[nj].dst = b + (bound[c] - 1); job[nj].len = 0;
+        nj++;
+        c = e;
+    }
+    if (nj) run_threads(fmt_work, job, sizeof(fmt_job), nj);
+    char *p = b;
+    for (int t = 0; t < nj; t++) { if (job[t].dst != p) memmove(p, job[t].dst, (size_t)job[t].len); p += job[t].len; }
+    free(bound);
     *p = 0;
     *text = b; *text_len = p - b;
     return PHX_OK;
