@@ -116,6 +116,19 @@ def edge_order(nd, ed):
 
 def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     """The --dump text of contig i of the batch `ann` last ran, as a list of lines (no newline)."""
+    nd, ed, weight = decimal_weights(ann, i, seq, start_codons)
+
+    def rep(v):
+        n = nd[v]
+        t = TNAME[int(n["type"])]
+        gene = t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS")
+        return "Node(%r,%r,%r,%r)" % (gene, t, int(n["frame"]), int(n["pos"]))
+
+    return ["%s\t%s\t%s" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), str(weight[k] * 1000)) for k in edge_order(nd, ed)]
+
+
+def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
+    """(node tap, edge tap, the reference's Decimal weight of every tapped edge, in tap order) of contig i."""
     if isinstance(seq, (bytes, bytearray)):
         seq = seq.decode()
     gl = ann.globals(i)
@@ -144,12 +157,6 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
             return pgap  # (the reference raises here; libphx reports such a contig through its status)
         return pgap
 
-    def rep(v):
-        n = nd[v]
-        t = TNAME[int(n["type"])]
-        gene = t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS")
-        return "Node(%r,%r,%r,%r)" % (gene, t, int(n["frame"]), int(n["pos"]))
-
     weight = []
     for e in ed:
         s, d = int(e["src"]), int(e["dst"])
@@ -174,4 +181,4 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
                 pst = Decimal((o_term(pd) + o_term(ps)) / 2)
                 w = _overlap(ps - pd + 3, diff, pst)
         weight.append(w)
-    return ["%s\t%s\t%s" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), str(weight[k] * 1000)) for k in edge_order(nd, ed)]
+    return nd, ed, weight

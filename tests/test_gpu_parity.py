@@ -807,6 +807,38 @@ def test_dump_text_is_byte_exact(case, pa):
     ann.close()
 
 
+def test_paths_from_decimal_derived_integers(pa):
+    """The reference hands fastpathz trunc(Decimal(w) * 1000) (28 digits), libphx solves on trunc(fp64(w) * 1000): the integers
+    differ in the low digits of large weights.  On fuzz contigs the Decimal weights (phanotate_amd/dump.py, the replay
+    behind the byte-exact --dump) solved with the golden generator's in-order Bellman-Ford in python ints give the node path
+    libphx returns (tools/decimal_check.py runs the same over thousands of contigs)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from decimal_check import solve
+    from fuzz_gpu import make
+    from phanotate_amd.dump import decimal_weights
+
+    rng = np.random.RandomState(77)
+    seqs = []
+    while len(seqs) < 40:
+        s = make(rng)
+        if len(s) <= 6000 and not set(s.lower()) - set("acgt"):
+            seqs.append(s)
+    ann = pa.Annotator()
+    res = ann.annotate(seqs)
+    checked = differing = 0
+    for i, (status, genes) in enumerate(res):
+        if status < 0 or ann.globals(i).n_node <= 2:
+            continue
+        nd, ed, w = decimal_weights(ann, i, seqs[i])
+        differing += sum(1 for k in range(len(ed)) if int(w[k] * 1000) != int(np.trunc(float(ed["w"][k]) * 1000.0)))
+        assert solve(nd, ed, w) == [int(x) for x in ann.path(i)[0]], i
+        checked += 1
+    assert checked >= 30 and differing > 0  # the two sets of integers do differ; the paths do not
+    ann.close()
+
+
 def test_bench_sharded_path_smoke():
     """bench.py's N > 1 code path (config 5: shard.partition, per-rank shards, timed host-to-host region with the flat gather to
     rank 0) with two ranks on this one GPU over gloo.  The numbers are meaningless; the line must come out and account for every contig."""
