@@ -62,7 +62,7 @@ struct phx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // side streams: independent SSSP classes overlap (0..2); k_wave_plan beside k_edges<true> (3)
-    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -77,7 +77,7 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_item;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item;
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
@@ -286,6 +286,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
+    b->cpre = (uint32_t *)c->b_cpre.p; b->bpre = (uint32_t *)c->b_bpre.p;
     b->bridge = (DBridge *)c->b_bridge.p;
     if (c->has_trna) { b->tnode = (const DTNode *)c->b_tnode.p; b->tedge = (const DTEdge *)c->b_tedge.p; b->tnid = (int32_t *)c->b_tnid.p; b->tbits = (uint64_t *)c->b_tbits.p; }
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
@@ -350,6 +351,11 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
+    { // prefix popcounts of the class and base bitmaps, one record per PHX_PRE_G words (k_bit_prefix): 6 planes of nw / G + 1 records of 32 bytes, 3 nw / G + 1 records of 16 bytes per contig
+        const size_t W = (size_t)(c->tot_words / PHX_BITMAP_WORDS_PER_NW);
+        if ((rc = ensure(c, c->b_cpre, (6 * (W / PHX_PRE_G + (size_t)c->n) + 2) * 32))) return rc;
+        if ((rc = ensure(c, c->b_bpre, (3 * W / PHX_PRE_G + (size_t)c->n + 2) * 16))) return rc;
+    }
     if ((rc = ensure(c, c->b_item, (size_t)(c->tot_items + 8) * 8))) return rc;
     if ((rc = ensure(c, c->b_bridge, (size_t)(c->tot_bridge + 8) * sizeof(DBridge)))) return rc;
     return PHX_OK;
@@ -442,7 +448,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     for (int a = 0; a < 4; a++)
         if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+        hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
@@ -474,7 +481,7 @@ void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -494,6 +501,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
     if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
     if (c->ev_join_nodes) (void)hipEventDestroy(c->ev_join_nodes);
+    if (c->ev_fork_pre) (void)hipEventDestroy(c->ev_fork_pre);
+    if (c->ev_join_pre) (void)hipEventDestroy(c->ev_join_pre);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -664,6 +673,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
+    // word-prefix popcounts of the bitmaps (for k_orf_stats) on a side stream, beside the ORF scan
+    HIPCHK(c, hipEventRecord(c->ev_fork_pre, s));
+    HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_pre, 0));
+    phxk_bit_prefix(&b, c->aux[0]);
+    HIPCHK(c, hipEventRecord(c->ev_join_pre, c->aux[0]));
     { StageTimer t(c, ST_ORF_COUNT); phxk_orf_count(&b, s); phxk_layout1(&b, s); }
     HIPCHK(c, hipGetLastError());
     DTotals *ht = c->h_tot;
@@ -699,7 +713,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipStreamWaitEvent(c->aux[1], c->ev_fork_nodes, 0));
     phxk_nodes(&b, c->aux[1]);
     HIPCHK(c, hipEventRecord(c->ev_join_nodes, c->aux[1]));
-    { StageTimer t(c, ST_ORF_STATS); phxk_orf_stats(&b, s); }
+    { StageTimer t(c, ST_ORF_STATS); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_pre, 0)); phxk_orf_stats(&b, s); }
     { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
     { StageTimer t(c, ST_NODES); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_nodes, 0)); phxk_node_attr(&b, s); }
     { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); phxk_layout2(&b, s); }

@@ -20,6 +20,7 @@
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
 #define PHX_N_CODON_BITMAPS 12 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple
+#define PHX_PRE_G 2 // bitmap words per prefix-popcount record (k_bit_prefix; a power of two <= 8: nw is a multiple of 8)
 #define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
 
 // codon classes, in the elif order of functions.py:198-215
@@ -72,7 +73,10 @@ struct DGrp {
     int32_t node; // device node id of the stop node
     int32_t frame;
     int32_t evkey; // position of the discovery event (0-based) or L + k for the k-th end fragment: reference insertion order
+    int32_t pick;  // the longest ORF of the group whose start codon is 'atg' (index within the group; -1: none): the one the GC frame plot trains on, functions.py:261-279
+    int32_t pad0;
 };
+static_assert(sizeof(DGrp) == 32, "group record");
 
 struct DBridge {
     int32_t last, base;
@@ -204,6 +208,7 @@ struct DBatch {
     const DTNode *tnode; // tRNA nodes / edges of the batch (null: none)
     const DTEdge *tedge;
     int32_t *tnid;      // per tRNA node: its device node id (k_node_build -> k_edges)
+    uint32_t *cpre, *bpre; // word-prefix popcounts of the GC-frame class bitmaps / of the base bitmaps (k_bit_prefix, phx_orf.inc)
     uint64_t *tbits;    // per contig 12*nw words at 4/3 * nbits_off: node bitmaps of the tRNA nodes, planes (strand, type) = forward start, forward stop, reverse start, reverse stop; zeroed every run
     DBridge *bridge;    // per contig bridge_cap entries: the uncovered runs of functions.py:334 (k_node_rank -> k_edges)
     // per ORF / group
@@ -245,6 +250,7 @@ extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream);
 void phxk_orf_count(const DBatch *b, void *stream);
 void phxk_orf_emit(const DBatch *b, void *stream);
+void phxk_bit_prefix(const DBatch *b, void *stream);
 void phxk_orf_stats(const DBatch *b, void *stream);
 void phxk_score(const DBatch *b, void *stream);
 void phxk_nodes(const DBatch *b, void *stream);

@@ -138,6 +138,7 @@ void phxk_orf_count(const DBatch *b, void *stream) {
     else hipLaunchKernelGGL((k_orf<false, ORF_COUNT_T>), dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b);
 }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, 6)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_bit_prefix(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, 8)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
