@@ -19,7 +19,7 @@
 #define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
-#define PHX_N_CODON_BITMAPS 12 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple
+#define PHX_N_CODON_BITMAPS 14 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple; 'atg' on the forward / reverse strand
 #define PHX_PRE_G 2 // bitmap words per prefix-popcount record (k_bit_prefix; a power of two <= 8: nw is a multiple of 8)
 #define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
 
@@ -57,7 +57,7 @@ struct DOrf { // what the scan knows about an ORF: one 16-byte store by k_orf<tr
     int8_t frame;        // +-1..3
     uint8_t rbs;         // score_rbs bin
     int8_t startidx;     // index into params.start or -1
-    uint8_t flags;       // bit0: Orf.start_codon() == 'atg'
+    uint8_t flags;       // bit0: Orf.start_codon() == 'atg'; bit1: pseudo-start (no start codon: startidx -1).  k_orf<true> leaves rbs, startidx and bit0 to k_orf_stats
     int32_t grp;         // contig-relative group index
 };
 struct DOrfStat { // its statistics: two 16-byte stores by k_orf_stats
