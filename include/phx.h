@@ -224,7 +224,9 @@ int phx_synth_contig(uint64_t seed, int64_t L, char *out);
  * in one uint32, class A=offsets 3-4 in bits 0-7, B=5-10, C=11-12, D=13-15); for CPU-side tests. */
 int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t *t4 /* [256] */, uint32_t *t3 /* [64] */);
 
-/* ---- host I/O of the CLI (no device needed; phx_host.c) ---- */
+/* ---- host I/O of the CLI (no device needed; phx_host.c) ----
+ * Files and texts beyond a few MB are parsed / formatted by worker threads (one per online core, at most 16; the environment
+ * variable PHX_HOST_THREADS overrides the count): the results do not depend on it. */
 /* FASTA, plain or gzip, read whole: what phanotate.py:32-35 gets from the external `genbank` package.  A record's name is the
  * first token of its header line (README.md:45); sequence lines are stripped of surrounding white space and joined, case kept
  * (the kernels lower-case); text before the first header is ignored. */
