@@ -216,7 +216,11 @@ def main():
         seqs = [read_golden_fasta(SINGLE[args.workload])]
         L_ = len(seqs[0])
         wl = "%s, one %d bp contig on one GPU (BASELINE config %d)" % (SINGLE[args.workload], L_, 2 if args.workload == "lambda" else 3)
-    ann = pa.Annotator(device=local_rank)  # the context's own stream; torch is only here for the process group and the barrier
+    # two contexts on this GPU (their own streams; torch is only here for the process group and the barrier): the first one does all
+    # the one-batch-at-a-time measurements, both take turns for the `two_batches_in_flight` lines.  (No third context: with more
+    # streams than hardware queues the streams of two contexts alias and their kernels stop overlapping.)
+    pipe = pa.Pipeline(device=local_rank, depth=2)
+    ann = pipe.anns[0]
 
     def barrier():
         if dist is not None:
@@ -277,6 +281,32 @@ def main():
     barrier()
     dt_host = max_over_ranks(time.perf_counter() - t0)
 
+    # ---- the same two regions with two batches in flight (pipeline.Pipeline: two contexts alternating on this GPU): what a
+    #      stream of batches — a job of many batches, the CLI on a large FASTA — moves at.  Extra lines: `value` stays the
+    #      one-batch-at-a-time figure, the one the roofline of the dominant kernel is measured in ----
+    for a2 in pipe.anns:
+        a2.annotate_flat(seqs)
+        for _ in range(max(3, args.warmup)):  # (the third run on a batch layout captures the graph the later ones launch)
+            a2.run()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        pipe.anns[k % 2].run_async()  # (a context with a run in flight collects it before it starts the next)
+    for a2 in pipe.anns:
+        a2.wait()
+    barrier()
+    dt_pipe = max_over_ranks(time.perf_counter() - t0)
+    dt_pipe_host = None
+    if world == 1:
+        for _ in pipe.run([seqs, seqs]):
+            pass
+        barrier()
+        t0 = time.perf_counter()
+        for _ in pipe.run([seqs] * args.steps):
+            pass
+        barrier()
+        dt_pipe_host = time.perf_counter() - t0
+
     if rank == 0:
         st_all, offs_all, genes_all = merged
         dom_ms = dom_total / max(dom_n, 1)
@@ -314,6 +344,13 @@ def main():
                 "ms_per_step": round(dt_host / args.steps * 1e3, 4),
                 "what": "SURVEY.md §8(d): host ASCII contigs -> host gene lists (phx_upload H2D + phx_run + phx_download_flat D2H%s), %d timed steps, barrier + synchronize around them, max over ranks" % ("" if world == 1 else " + gather of the flat gene arrays to rank 0", args.steps),
             },
+            "two_batches_in_flight": dict({
+                "value": round(bp_total * args.steps / dt_pipe / 1e6, 3),
+                "unit": "Mbp/s",
+                "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),
+                "what": "the timed region of `value` with two contexts on their own streams taking the steps in turn (phx_run_async / phx_wait): the shortest-path kernel of one step runs beside the throughput kernels of the next; every step is still one whole pass over the resident batch",
+            }, **({} if dt_pipe_host is None else {"host_to_host": {"value": round(bp_total * args.steps / dt_pipe_host / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(dt_pipe_host / args.steps * 1e3, 4),
+                                                   "what": "host ASCII -> host gene lists for a stream of batches through pipeline.Pipeline: the upload of a batch overlaps the kernels of the one before"}})),
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
@@ -364,7 +401,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ann.close()
+    pipe.close()
 
 
 if __name__ == "__main__":

@@ -5,5 +5,6 @@ Importing this package never falls back to a CPU implementation: `_lib.lib()` ra
 shared library has not been built, and phx_create fails without a HIP device.
 """
 from .api import Annotator, PhxError, make_params, synth_contig  # noqa: F401
+from .pipeline import Pipeline  # noqa: F401
 
-__version__ = "0.2.0"
+__version__ = "0.2.1"

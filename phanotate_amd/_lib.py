@@ -110,6 +110,8 @@ def lib():
         "phx_attach": (C.c_int, [vp, i32, vp, P(i64)]),
         "phx_set_trnas": (C.c_int, [vp, vp, vp, vp]),
         "phx_run": (C.c_int, [vp]),
+        "phx_run_async": (C.c_int, [vp]),
+        "phx_wait": (C.c_int, [vp]),
         "phx_download": (C.c_int, [vp, P(Result)]),
         "phx_download_flat": (C.c_int, [vp, vp, i64, vp, vp, P(i64)]),
         "phx_tap_globals": (C.c_int, [vp, i32, P(Globals)]),
@@ -145,7 +147,7 @@ def lib():
 
 
 EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_create_ex", "phx_destroy",
-           "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_download", "phx_download_flat", "phx_tap_globals",
+           "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_run_async", "phx_wait", "phx_download", "phx_download_flat", "phx_tap_globals",
            "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
            "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table", "phx_fasta_read", "phx_fasta_count",
            "phx_fasta_record", "phx_fasta_arrays", "phx_fasta_free", "phx_format_tabular", "phx_free_text"]

@@ -132,6 +132,14 @@ class Annotator:
     def run(self):
         self._chk(self.L.phx_run(self.h), "phx_run")
 
+    def run_async(self):
+        """Enqueue the run and return (phx_run_async); wait() — or any other call on this context — collects it.  With two
+        contexts alternating, one batch's upload and kernels overlap the other's shortest-path kernel: see pipeline.Pipeline."""
+        self._chk(self.L.phx_run_async(self.h), "phx_run_async")
+
+    def wait(self):
+        self._chk(self.L.phx_wait(self.h), "phx_wait")
+
     def download_flat(self):
         """(status int32[n], offsets int64[n+1], genes structured array[total]): genes of contig i are genes[offsets[i]:offsets[i+1]]
         in path order (phx_download_flat: no per-contig allocation)."""

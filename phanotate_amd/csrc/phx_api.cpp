@@ -62,6 +62,9 @@ struct phx_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; // side streams: independent SSSP classes overlap (0..2); k_wave_plan beside k_edges<true> (3)
+    bool in_flight = false;      // phx_run_async has enqueued a run that phx_wait has not collected yet
+    int pend_mask = 0;
+    int64_t pend_lds[4] = {0, 0, 0, 0};
     hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
@@ -307,6 +310,8 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->gene_total = (uint32_t *)c->b_gtot.p;
 }
 
+int settle(phx_ctx *c); // brings a run enqueued by phx_run_async to its end (below)
+
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     c->has_trna = false; c->h_tnode.clear();
@@ -480,6 +485,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
 void phx_destroy(phx_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
@@ -510,6 +516,7 @@ void phx_destroy(phx_ctx *c) {
 int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len) {
     if (!c || n < 0 || (n > 0 && (!seq || !len))) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_flight) (void)settle(c); // a run still in flight reads the buffers this call replaces
     c->attached = nullptr;
     int rc = set_batch_layout(c, n, len, nullptr);
     if (rc) return rc;
@@ -576,6 +583,7 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
     if (!c) return PHX_E_ARG;
     if (!c->uploaded) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_flight) (void)settle(c);
     c->ran = false; c->graph_valid = false; c->meta0_dirty = true; c->runs_on_layout = 0;
     c->has_trna = false; c->h_tnode.clear();
     for (DMeta &m : c->meta) { m.n_tnode = 0; m.n_tedge = 0; m.tn_off = 0; m.te_off = 0; if (m.status == PHX_S_PARALLEL) m.status = 0; }
@@ -635,6 +643,7 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
 int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offsets) {
     if (!c || n < 0 || !offsets || (n > 0 && !d_ascii)) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_flight) (void)settle(c);
     int rc = set_batch_layout(c, n, nullptr, offsets);
     if (rc) return rc;
     c->attached = d_ascii;
@@ -813,7 +822,7 @@ void drop_graph(phx_ctx *c) {
 // enqueued at once against the buffers the context already has — as one HIP graph launch when the previous run's graph
 // still applies (same batch layout, buffers, solver classes) —; the layout kernels flag a batch that does not fit,
 // later kernels then do nothing, and the caller runs again with `learn`.
-int run_once(phx_ctx *c, bool learn) {
+int launch_once(phx_ctx *c, bool learn) {
     int rc;
     hipStream_t s = c->stream;
     if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
@@ -874,6 +883,16 @@ int run_once(phx_ctx *c, bool learn) {
         }
     }
     if (!launched && (rc = enqueue_run(c, learn, mask, lds))) return rc;
+    c->pend_mask = mask;
+    for (int k = 0; k < 4; k++) c->pend_lds[k] = lds[k];
+    return PHX_OK;
+}
+
+// ... and what follows once the stream has drained: the totals the run left on the host say whether it fitted
+int finish_once(phx_ctx *c) {
+    hipStream_t s = c->stream;
+    const int mask = c->pend_mask;
+    const int64_t *lds = c->pend_lds;
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
     const DTotals *ht = c->h_tot;
@@ -889,6 +908,23 @@ int run_once(phx_ctx *c, bool learn) {
     c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
     c->have_plan = true;
     c->runs_on_layout++;
+    return PHX_OK;
+}
+
+int run_once(phx_ctx *c, bool learn) {
+    const int rc = launch_once(c, learn);
+    return rc ? rc : finish_once(c);
+}
+
+// a run enqueued by phx_run_async is brought to its end before anything else touches the context
+int settle(phx_ctx *c) {
+    if (!c->in_flight) return PHX_OK;
+    c->in_flight = false;
+    int rc = finish_once(c);
+    for (int attempt = 0; rc == kRetry && attempt < 3; attempt++) rc = run_once(c, true);
+    if (rc == kRetry) { c->err = "batch layout did not settle"; return PHX_E_STATE; }
+    if (rc) return rc;
+    c->ran = true;
     return PHX_OK;
 }
 
@@ -928,10 +964,33 @@ static void dev_report(phx_ctx *c) {
 }
 #endif
 
+int phx_run_async(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (!c->uploaded) return PHX_E_STATE;
+    // the first run of a context (and one after a batch outgrew its buffers) sizes the buffers between kernels: synchronous
+    if (!c->have_plan || c->always_sync || c->n == 0) return phx_run(c);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = settle(c);
+    if (rc) return rc;
+    c->ran = false;
+    c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
+    if ((rc = launch_once(c, false))) return rc;
+    c->in_flight = true;
+    return PHX_OK;
+}
+
+int phx_wait(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_flight) return settle(c);
+    return c->ran ? PHX_OK : PHX_E_STATE;
+}
+
 int phx_run(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (!c->uploaded) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rs = settle(c); if (rs) return rs; }
     c->ran = false;
     c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
     if (c->n == 0) { c->ran = true; return PHX_OK; }
@@ -948,6 +1007,7 @@ int phx_run(phx_ctx *c) {
 
 int phx_download(phx_ctx *c, phx_result *out) {
     if (!c || (!out && c->n > 0)) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     int64_t total = 0;
@@ -978,6 +1038,7 @@ int phx_download(phx_ctx *c, phx_result *out) {
 
 int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets, int32_t *status, int64_t *total_out) {
     if (!c || (c->n > 0 && (!offsets || !status))) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     int64_t total = 0, hi = 0;
@@ -1023,6 +1084,7 @@ void phx_free_results(phx_result *res, int32_t n) {
 // ---- taps ----
 #define TAP_PRE(c, contig)                                            \
     if (!(c)) return PHX_E_ARG;                                       \
+    if ((c)->in_flight) { const int rs_ = phx_wait(c); if (rs_) return rs_; } \
     if (!(c)->ran) return PHX_E_STATE;                                \
     if ((contig) < 0 || (contig) >= (c)->n) return PHX_E_ARG;         \
     HIPCHK(c, hipSetDevice((c)->device));                             \
@@ -1230,6 +1292,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     if (!(n_limbs == 2 || n_limbs == 4 || n_limbs == 8 || n_limbs == 17)) return PHX_E_ARG;
     if (source < 0 || source >= V || target < 0 || target >= V || source == target) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->in_flight) (void)settle(c);
     *n_path = 0;
     // device node order: everything else in given order, then source (V-2), then target (V-1)
     std::vector<int32_t> to_dev((size_t)V), to_user((size_t)V);
@@ -1337,6 +1400,7 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
 int phx_batch_sizes(phx_ctx *c, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge) {
     if (!c) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (L) *L = c->totalL;
     if (n_orf) *n_orf = c->tot_orf;
     if (n_node) *n_node = c->tot_node;

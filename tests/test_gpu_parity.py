@@ -839,6 +839,45 @@ def test_paths_from_decimal_derived_integers(pa):
     ann.close()
 
 
+def test_batches_in_flight_equal_one_after_the_other(pa):
+    """phx_run_async / phx_wait and pipeline.Pipeline (two contexts alternating on one GPU): a stream of different batches —
+    growing sizes, so that a context finds its buffers too small in phx_wait and runs again; an empty batch; a contig with a bad
+    letter — gives exactly what one Annotator gives batch by batch.  Calls on a context with a run in flight wait for it."""
+    rng = np.random.RandomState(3)
+
+    def batch(n, length, seed0):
+        return [pa.synth_contig(seed0 + k, int(length * rng.uniform(0.6, 1.4))) for k in range(n)]
+
+    batches = [batch(3, 6000, 10), batch(40, 12000, 100), [], batch(1, 50000, 7), batch(150, 3000, 300) + [b"acgtxacgt" * 50], batch(6, 25000, 900),
+               batch(60, 15000, 2000), batch(2, 2000, 5)]
+    one = pa.Annotator()
+    want = [one.annotate_flat(b) for b in batches]
+    with pa.Pipeline(depth=2) as pipe:
+        got = pipe.annotate_flat(batches)
+        assert len(got) == len(want)
+        for (ws, wo, wg), (gs, go, gg) in zip(want, got):
+            assert np.array_equal(ws, gs) and np.array_equal(wo, go)
+            assert wg.tobytes() == gg.tobytes()
+        again = list(pipe.run(batches[::-1]))  # the contexts are warm now: every run is asynchronous
+        for (ws, wo, wg), (gs, go, gg) in zip(want[::-1], again):
+            assert np.array_equal(ws, gs) and np.array_equal(wo, go) and wg.tobytes() == gg.tobytes()
+    assert any((w[0] < 0).any() for w in want)  # the bad-letter contig kept its status, its batch its other results
+    # a run in flight: taps, downloads and a new upload wait for it; wait() twice is harmless
+    a = pa.Annotator()
+    a.annotate_flat(batches[1])
+    a.upload(batches[5])
+    a.run_async()
+    n_node = a.globals(0).n_node  # tap on a context with a run in flight
+    a.wait(); a.wait()
+    st, offs, genes = a.download_flat()
+    assert n_node > 2 and genes.tobytes() == want[5][2].tobytes()
+    a.run_async()
+    a.upload(batches[3])  # replaces the batch under a run in flight: the run is collected first
+    a.run_async()
+    assert a.download_flat()[2].tobytes() == want[3][2].tobytes()
+    a.close(); one.close()
+
+
 def test_bench_sharded_path_smoke():
     """bench.py's N > 1 code path (config 5: shard.partition, per-rank shards, timed host-to-host region with the flat gather to
     rank 0) with two ranks on this one GPU over gloo.  The numbers are meaningless; the line must come out and account for every contig."""
