@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--cli-contigs", type=int, default=1000, help="contigs of the end-to-end phanotate.py run (0: skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-contig lines, the CPU baselines and the CLI run")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the two_batches_in_flight lines (profiling passes: every launch then belongs to the one-batch-at-a-time regions)")
     ap.add_argument("--smoke-single-device", action="store_true",
                     help="N > 1 ranks on ONE GPU over gloo: exercises the sharded code path (partition, per-rank shards, flat gather) where no multi-GPU node is at hand; its numbers mean nothing")
     args = ap.parse_args()
@@ -284,20 +285,21 @@ def main():
     # ---- the same two regions with two batches in flight (pipeline.Pipeline: two contexts alternating on this GPU): what a
     #      stream of batches — a job of many batches, the CLI on a large FASTA — moves at.  Extra lines: `value` stays the
     #      one-batch-at-a-time figure, the one the roofline of the dominant kernel is measured in ----
-    for a2 in pipe.anns:
-        a2.annotate_flat(seqs)
-        for _ in range(max(3, args.warmup)):  # (the third run on a batch layout captures the graph the later ones launch)
-            a2.run()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        pipe.anns[k % 2].run_async()  # (a context with a run in flight collects it before it starts the next)
-    for a2 in pipe.anns:
-        a2.wait()
-    barrier()
-    dt_pipe = max_over_ranks(time.perf_counter() - t0)
-    dt_pipe_host = None
-    if world == 1:
+    dt_pipe = dt_pipe_host = None
+    if not args.no_pipeline:
+        for a2 in pipe.anns:
+            a2.annotate_flat(seqs)
+            for _ in range(max(3, args.warmup)):  # (the third run on a batch layout captures the graph the later ones launch)
+                a2.run()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            pipe.anns[k % 2].run_async()  # (a context with a run in flight collects it before it starts the next)
+        for a2 in pipe.anns:
+            a2.wait()
+        barrier()
+        dt_pipe = max_over_ranks(time.perf_counter() - t0)
+    if world == 1 and not args.no_pipeline:
         for _ in pipe.run([seqs, seqs]):
             pass
         barrier()
@@ -344,7 +346,7 @@ def main():
                 "ms_per_step": round(dt_host / args.steps * 1e3, 4),
                 "what": "SURVEY.md §8(d): host ASCII contigs -> host gene lists (phx_upload H2D + phx_run + phx_download_flat D2H%s), %d timed steps, barrier + synchronize around them, max over ranks" % ("" if world == 1 else " + gather of the flat gene arrays to rank 0", args.steps),
             },
-            "two_batches_in_flight": dict({
+            "two_batches_in_flight": None if dt_pipe is None else dict({
                 "value": round(bp_total * args.steps / dt_pipe / 1e6, 3),
                 "unit": "Mbp/s",
                 "ms_per_step": round(dt_pipe / args.steps * 1e3, 4),
