@@ -93,7 +93,7 @@ struct phx_ctx {
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
-    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -281,6 +281,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->mean_len = c->n > 0 ? c->totalL / c->n : 0;
     b->meta = (DMeta *)c->b_meta.p;
     b->tot = (DTotals *)c->b_tot.p;
+    b->lpart = (int64_t *)c->b_lpart.p;
     current_caps(c, &b->caps);
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
@@ -355,6 +356,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
+    if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
     { // prefix popcounts of the class and base bitmaps, one record per PHX_PRE_G words (k_bit_prefix): 6 planes of nw / G + 1 records of 32 bytes, 3 nw / G + 1 records of 16 bytes per contig
         const size_t W = (size_t)(c->tot_words / PHX_BITMAP_WORDS_PER_NW);
@@ -488,7 +490,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);

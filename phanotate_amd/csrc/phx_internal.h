@@ -193,6 +193,7 @@ struct DBatch {
     int64_t mean_len;   // mean contig length of the batch (launch geometry of the per-contig kernels)
     DMeta *meta;
     DTotals *tot;
+    int64_t *lpart;     // k_layout*_a -> _b: per workgroup of 256 contigs the four totals (batches beyond 1024 contigs)
     DCaps caps;
     const DParams *params;
     const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;

@@ -178,8 +178,19 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
 }
 
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
-void phxk_layout1(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout1, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); }
-void phxk_layout2(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_layout2, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); }
+// one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs
+void phxk_layout1(const DBatch *b, void *stream) {
+    if (b->n_contig <= LAYOUT_T) { hipLaunchKernelGGL(k_layout1, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); return; }
+    const unsigned g = (unsigned)((b->n_contig + LMB_T - 1) / LMB_T);
+    hipLaunchKernelGGL(k_layout1_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_layout1_b, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+}
+void phxk_layout2(const DBatch *b, void *stream) {
+    if (b->n_contig <= LAYOUT_T) { hipLaunchKernelGGL(k_layout2, dim3(1), dim3(LAYOUT_T), 0, (hipStream_t)stream, *b); return; }
+    const unsigned g = (unsigned)((b->n_contig + LMB_T - 1) / LMB_T);
+    hipLaunchKernelGGL(k_layout2_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_layout2_b, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+}
 
 int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
