@@ -256,10 +256,15 @@ int64_t cap_of(const DevBuf &b, size_t elem, int64_t reserve) {
     const int64_t k = (int64_t)((b.cap - 2048) / elem) - reserve;
     return k > 0 ? k : 0;
 }
+// Batches beyond 4096 contigs keep the gene records in two halves of b_genes: every contig's own place in the first (no shared
+// counter: 20 000 atomics on one address were 0.25 ms), the packed records in the second (k_gene_pack, ~0.03 ms).  Entries per half:
+static inline bool gene_pack(const phx_ctx *c) { return c->n > 4096; }
+static inline int64_t gene_half(const phx_ctx *c) { return (int64_t)(c->b_genes.cap / sizeof(DGene)) / 2; }
+
 void current_caps(const phx_ctx *c, DCaps *k) {
     const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
     k->orf = std::min(std::min(cap_of(c->b_orf, sizeof(DOrf), 1), cap_of(c->b_ostat, sizeof(DOrfStat), 1)), std::min(cap_of(c->b_oweight, 8, 1), cap_of(c->b_onode, 4, 1)));
-    k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, 2 * sizeof(DGene), 1)); // a path k_inorder replaces may take new gene slots
+    k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, 2 * sizeof(DGene), 1) - (int64_t)c->h_tnode.size()); // a path k_inorder replaces may take new gene slots; tRNA features are genes too
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
     for (const DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist}) v = std::min(v, cap_of(*q, 4, 8));
     v = std::min(v, cap_of(c->b_no, 8, 8));
@@ -308,6 +313,8 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
+    b->gpack = gene_pack(c) ? 1 : 0;
+    b->genes_c = b->genes ? b->genes + gene_half(c) : nullptr;
     b->gene_total = (uint32_t *)c->b_gtot.p;
 }
 
@@ -702,7 +709,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_oweight, 8 * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_onode, 4 * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
-        if ((rc = ensure(c, c->b_genes, 2 * sizeof(DGene) * G))) return rc;
+        if ((rc = ensure(c, c->b_genes, 2 * sizeof(DGene) * (G + c->h_tnode.size() + 8)))) return rc;
         if ((rc = ensure(c, c->b_node, NV * sizeof(DNode)))) return rc;
         for (DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist})
             if ((rc = ensure(c, *q, NV * 4))) return rc;
@@ -803,6 +810,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         int nlm = 0;
         for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
         phxk_inorder(&b, nlm, s);
+        if (b.gpack) phxk_gene_pack(&b, s);
     } // equal-length alternatives: the parents of the reference's relaxation order
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
@@ -1016,7 +1024,7 @@ int phx_download(phx_ctx *c, phx_result *out) {
     for (const DMeta &m : c->meta) total = std::max<int64_t>(total, m.gene_off + m.n_genes);
     c->h_genes.resize((size_t)total);
     if (total) {
-        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), c->b_genes.p, sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < c->n; i++) {
@@ -1055,7 +1063,7 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     if (cap < total) return PHX_E_ARG;
     c->h_genes.resize((size_t)hi);
     if (hi) {
-        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), c->b_genes.p, sizeof(DGene) * (size_t)hi, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)hi, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     static_assert(sizeof(DGene) == sizeof(phx_gene), "device and ABI gene records have the same layout");

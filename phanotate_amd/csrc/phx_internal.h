@@ -242,6 +242,8 @@ struct DBatch {
     int32_t *path;
     DGene *genes;
     uint32_t *gene_total;
+    int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c
+    DGene *genes_c;
 };
 
 #ifdef __cplusplus
@@ -265,7 +267,8 @@ size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
-void phxk_inorder(const DBatch *b, int nl_mask, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
+void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
+void phxk_gene_pack(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }
 #endif

@@ -140,7 +140,7 @@ void phxk_orf_count(const DBatch *b, void *stream) {
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, 6)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_bit_prefix(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, 8)), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(b->mean_len >= 8192 ? NT : 64), 0, (hipStream_t)stream, *b); }
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
@@ -169,14 +169,31 @@ void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
 
 // nl_mask: bit k set = some contig of the batch has 2 / 4 / 8 / 17 limbs (k = 0..3)
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
-    dim3 g(b->n_contig), t(IO_T);
+    dim3 g(b->n_contig);
     hipStream_t s = (hipStream_t)stream;
-    if (nl_mask & 1) hipLaunchKernelGGL(k_inorder<2>, g, t, 0, s, *b);
-    if (nl_mask & 2) hipLaunchKernelGGL(k_inorder<4>, g, t, 0, s, *b);
-    if (nl_mask & 4) hipLaunchKernelGGL(k_inorder<8>, g, t, 0, s, *b);
-    if (nl_mask & 8) hipLaunchKernelGGL(k_inorder<17>, g, t, 0, s, *b);
+    // the benchmark's kind of contig: 256 threads and the full chunk of LDS for the path walk; batches of short contigs (a workgroup is
+    // one contig with a hundred nodes): one wavefront and a quarter of the LDS, so that four times as many contigs are in flight
+    const bool small = b->mean_len < 8192;
+    const int walk_n = small ? IO_WALK / 4 : IO_WALK, path_n = small ? IO_PATH / 4 : IO_PATH;
+    const size_t dyn = (size_t)(walk_n + path_n) * 4;
+    if (small) {
+        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
+    } else {
+        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
+    }
 }
 
+void phxk_gene_pack(const DBatch *b, void *stream) {
+    const unsigned g = (unsigned)((b->n_contig + LMB_T - 1) / LMB_T);
+    hipLaunchKernelGGL(k_gene_pack_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_gene_pack_b, dim3(g, 8), dim3(LMB_T), 0, (hipStream_t)stream, *b);
+}
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
 // one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs
 void phxk_layout1(const DBatch *b, void *stream) {

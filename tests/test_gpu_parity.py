@@ -839,6 +839,49 @@ def test_paths_from_decimal_derived_integers(pa):
     ann.close()
 
 
+def test_batch_of_thousands_of_short_contigs(pa, oracle):
+    """Batches beyond 1024 / 4096 contigs take other kernels in places: the layout scans in two passes (k_layout*_a / _b), gene records at
+    a fixed place per contig + k_gene_pack instead of one shared counter, one-wavefront workgroups in k_inorder / k_score for short
+    contigs.  6000 short contigs (tRNA hits on some, a bad letter in a few) in ONE batch give, contig by contig, what batches of 500 give,
+    and a sample of them equals the oracle."""
+    rng = np.random.RandomState(11)
+    seqs, trnas = [], []
+    for i in range(6000):
+        L = int(rng.choice([150, 400, 900, 1600, 2500, 5000]))
+        s = pa.synth_contig(40000 + i, L)
+        if i % 997 == 0:
+            s = s[:50] + b"x" + s[51:]
+        seqs.append(s)
+        hits = []
+        if i % 7 == 0 and L >= 900:
+            a = int(rng.randint(30, L - 200))
+            hits.append((a, a + 72) if i % 14 else (a + 72, a))
+        trnas.append(hits)
+    big = pa.Annotator()
+    got = big.annotate(seqs, trnas=trnas)
+    small = pa.Annotator()
+    want = []
+    for k in range(0, len(seqs), 500):
+        want += small.annotate(seqs[k:k + 500], trnas=trnas[k:k + 500])
+    assert len(got) == len(want) == 6000
+    n_genes = 0
+    for i, ((gs, gg), (ws, wg)) in enumerate(zip(got, want)):
+        assert gs == ws, i
+        assert gg.tobytes() == wg.tobytes(), i
+        n_genes += len(gg)
+    assert n_genes > 6000 and sum(1 for st, _ in got if st < 0) >= 6
+    for i in rng.choice(6000, 60, replace=False):
+        o = oracle.run(seqs[i].decode(), trnas=trnas[i])
+        st, g = got[i]
+        if o["status"] == -7:  # beyond the oracle's 256-bit integers
+            continue
+        if o["status"] < 0:
+            assert st == o["status"], i
+            continue
+        assert st >= 0 and g["left"].tolist() == np.asarray(o["gene_left"]).tolist() and g["right"].tolist() == np.asarray(o["gene_right"]).tolist(), i
+    big.close(); small.close()
+
+
 def test_batches_in_flight_equal_one_after_the_other(pa):
     """phx_run_async / phx_wait and pipeline.Pipeline (two contexts alternating on one GPU): a stream of different batches —
     growing sizes, so that a context finds its buffers too small in phx_wait and runs again; an empty batch; a contig with a bad
