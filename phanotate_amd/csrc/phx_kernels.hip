@@ -171,21 +171,19 @@ void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
     dim3 g(b->n_contig);
     hipStream_t s = (hipStream_t)stream;
-    // the benchmark's kind of contig: 256 threads and the full chunk of LDS for the path walk; batches of short contigs (a workgroup is
-    // one contig with a hundred nodes): one wavefront and a quarter of the LDS, so that four times as many contigs are in flight
+    // the benchmark's kind of contig: 256 threads; batches of short contigs (a workgroup is one contig with a hundred nodes): one wavefront
+    // and a quarter of the LDS for the path walk, so that four times as many contigs are in flight
     const bool small = b->mean_len < 8192;
-    const int walk_n = small ? IO_WALK / 4 : IO_WALK, path_n = small ? IO_PATH / 4 : IO_PATH;
-    const size_t dyn = (size_t)(walk_n + path_n) * 4;
     if (small) {
-        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, 64>), g, dim3(64), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, 64>), g, dim3(64), 0, s, *b);
+        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, 64>), g, dim3(64), 0, s, *b);
+        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, 64>), g, dim3(64), 0, s, *b);
+        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, 64>), g, dim3(64), 0, s, *b);
     } else {
-        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
-        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, IO_T_FULL>), g, dim3(IO_T_FULL), dyn, s, *b, walk_n, path_n);
+        if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
+        if (nl_mask & 2) hipLaunchKernelGGL((k_inorder<4, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
+        if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
+        if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
     }
 }
 
