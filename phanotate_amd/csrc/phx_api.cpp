@@ -76,7 +76,10 @@ struct phx_ctx {
     bool uploaded = false, ran = false;
     int64_t totalL = 0, tot_orf = 0, tot_grp = 0, tot_node = 0, tot_edge = 0;
     int n_limbs = 0;
-    MetaBuf meta;
+    MetaBuf meta;            // host copy of the per-contig records: the layout as the host set it; the device's values after fetch_meta()
+    bool meta_stale = false; // a run has finished since c->meta was last fetched
+    DRes *res = nullptr;     // pinned: status / gene count / first gene of every contig after a run
+    size_t res_cap = 0;
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
@@ -93,7 +96,7 @@ struct phx_ctx {
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
-    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -287,6 +290,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->meta = (DMeta *)c->b_meta.p;
     b->tot = (DTotals *)c->b_tot.p;
     b->lpart = (int64_t *)c->b_lpart.p;
+    b->res = (DRes *)c->b_res.p;
     current_caps(c, &b->caps);
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
@@ -319,9 +323,17 @@ void fill_batch(phx_ctx *c, DBatch *b) {
 }
 
 int settle(phx_ctx *c); // brings a run enqueued by phx_run_async to its end (below)
+// the device's per-contig records, for the taps (a run only brings DRes over)
+int fetch_meta(phx_ctx *c) {
+    if (!c->meta_stale || c->n == 0) return PHX_OK;
+    HIPCHK(c, hipMemcpy(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)c->n, hipMemcpyDeviceToHost));
+    c->meta_stale = false;
+    return PHX_OK;
+}
 
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
+    c->meta_stale = false;
     c->has_trna = false; c->h_tnode.clear();
     if (n < 0) return PHX_E_ARG;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
@@ -364,6 +376,14 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
+    if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes)))) return rc;
+    if (c->res_cap < (size_t)c->n + 1) {
+        if (c->res) (void)hipHostFree(c->res);
+        c->res = nullptr; c->res_cap = 0;
+        const size_t want = (size_t)c->n + (size_t)c->n / 4 + 16;
+        if (hipHostMalloc((void **)&c->res, want * sizeof(DRes), hipHostMallocDefault) != hipSuccess) { c->res = nullptr; c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
+        c->res_cap = want;
+    }
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
     { // prefix popcounts of the class and base bitmaps, one record per PHX_PRE_G words (k_bit_prefix): 6 planes of nw / G + 1 records of 32 bytes, 3 nw / G + 1 records of 16 bytes per contig
         const size_t W = (size_t)(c->tot_words / PHX_BITMAP_WORDS_PER_NW);
@@ -497,7 +517,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -509,6 +529,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->d_t3) (void)hipFree(c->d_t3);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->meta.release();
+    if (c->res) (void)hipHostFree(c->res);
+    c->res = nullptr; c->res_cap = 0;
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int a = 0; a < 4; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
@@ -815,7 +837,8 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->meta.data(), c->b_meta.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToHost, s));
+        phxk_results(&b, s);
+        HIPCHK(c, hipMemcpyAsync(c->res, c->b_res.p, sizeof(DRes) * (size_t)n, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s));
     }
     return PHX_OK;
@@ -905,6 +928,7 @@ int finish_once(phx_ctx *c) {
     const int64_t *lds = c->pend_lds;
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
+    c->meta_stale = true;
     const DTotals *ht = c->h_tot;
     c->tie_seen = std::max(c->tie_seen, ht->tie_need);
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
@@ -945,6 +969,7 @@ int settle(phx_ctx *c) {
 // the per-contig records, printed when PHX_DEBUG_WAVE / PHX_DEBUG_SSSP / PHX_DEBUG_CENSUS is set
 static void dev_report(phx_ctx *c) {
     const int n = c->n;
+    (void)fetch_meta(c);
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_WAVE")) {
         int nfb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nw = 0;
@@ -1021,14 +1046,14 @@ int phx_download(phx_ctx *c, phx_result *out) {
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     int64_t total = 0;
-    for (const DMeta &m : c->meta) total = std::max<int64_t>(total, m.gene_off + m.n_genes);
+    for (int i = 0; i < c->n; i++) total = std::max<int64_t>(total, c->res[i].gene_off + c->res[i].n_genes);
     c->h_genes.resize((size_t)total);
     if (total) {
         HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < c->n; i++) {
-        const DMeta &m = c->meta[(size_t)i];
+        const DRes &m = c->res[(size_t)i];
         out[i].status = m.status;
         out[i].n_genes = m.status < 0 ? 0 : m.n_genes;
         out[i].genes = nullptr;
@@ -1052,11 +1077,11 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     int64_t total = 0, hi = 0;
-    for (const DMeta &m : c->meta) { total += m.status < 0 ? 0 : m.n_genes; hi = std::max<int64_t>(hi, m.gene_off + m.n_genes); }
+    for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; total += m.status < 0 ? 0 : m.n_genes; hi = std::max<int64_t>(hi, m.gene_off + m.n_genes); }
     if (total_out) *total_out = total;
     if (!genes) { // size query
         int64_t o = 0;
-        for (int i = 0; i < c->n; i++) { const DMeta &m = c->meta[(size_t)i]; offsets[i] = o; status[i] = m.status; o += m.status < 0 ? 0 : m.n_genes; }
+        for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; offsets[i] = o; status[i] = m.status; o += m.status < 0 ? 0 : m.n_genes; }
         if (c->n >= 0 && offsets) offsets[c->n] = o;
         return PHX_OK;
     }
@@ -1069,7 +1094,7 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     static_assert(sizeof(DGene) == sizeof(phx_gene), "device and ABI gene records have the same layout");
     int64_t o = 0;
     for (int i = 0; i < c->n; i++) {
-        const DMeta &m = c->meta[(size_t)i];
+        const DRes &m = c->res[(size_t)i];
         const int64_t k = m.status < 0 ? 0 : m.n_genes;
         offsets[i] = o; status[i] = m.status;
         if (k) memcpy(genes + o, &c->h_genes[(size_t)m.gene_off], sizeof(phx_gene) * (size_t)k);
@@ -1098,6 +1123,7 @@ void phx_free_results(phx_result *res, int32_t n) {
     if (!(c)->ran) return PHX_E_STATE;                                \
     if ((contig) < 0 || (contig) >= (c)->n) return PHX_E_ARG;         \
     HIPCHK(c, hipSetDevice((c)->device));                             \
+    { const int rf_ = fetch_meta(c); if (rf_) return rf_; }           \
     const DMeta &m = (c)->meta[(size_t)(contig)];
 
 extern "C" void phxk_sssp_only(const DBatch *b, int n_limbs, void *stream);

@@ -139,6 +139,12 @@ struct DMeta { // one per contig
     int32_t pad0;
 };
 
+// What the host needs of a contig after every run (the full DMeta record, 0.5 KB, comes over only when a tap asks for it)
+struct DRes {
+    int32_t status, n_genes;
+    int64_t gene_off;
+};
+
 struct DTile {
     int32_t contig;
     int32_t p0;
@@ -193,6 +199,7 @@ struct DBatch {
     int64_t mean_len;   // mean contig length of the batch (launch geometry of the per-contig kernels)
     DMeta *meta;
     DTotals *tot;
+    DRes *res;          // per contig: status, gene count, first gene record (k_results, the last kernel of a run)
     int64_t *lpart;     // k_layout*_a -> _b: per workgroup of 256 contigs the four totals (batches beyond 1024 contigs)
     DCaps caps;
     const DParams *params;
@@ -268,7 +275,8 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
-void phxk_gene_pack(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
+void phxk_gene_pack(const DBatch *b, void *stream);
+void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }
 #endif

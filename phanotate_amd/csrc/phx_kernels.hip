@@ -192,6 +192,7 @@ void phxk_gene_pack(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_gene_pack_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_gene_pack_b, dim3(g, 8), dim3(LMB_T), 0, (hipStream_t)stream, *b);
 }
+void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
 // one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs
 void phxk_layout1(const DBatch *b, void *stream) {
