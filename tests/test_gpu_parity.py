@@ -918,7 +918,9 @@ def test_batches_in_flight_equal_one_after_the_other(pa):
     a.upload(batches[3])  # replaces the batch under a run in flight: the run is collected first
     a.run_async()
     assert a.download_flat()[2].tobytes() == want[3][2].tobytes()
-    a.close(); one.close()
+    a.run_async()
+    a.close()  # destroying a context with a run in flight drains its stream first
+    one.close()
 
 
 def test_bench_sharded_path_smoke():
