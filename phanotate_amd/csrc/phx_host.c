@@ -5,6 +5,7 @@
  * phanotate.py:32-35: every record's name = first token of the header, README.md:45) and the tabular writer
  * phanotate_modules/locus.py:39-56.
  */
+#define _DEFAULT_SOURCE
 #define _POSIX_C_SOURCE 200809L
 #include <ctype.h>
 #include <fcntl.h>
@@ -13,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -44,7 +46,29 @@ static void run_threads(void *(*fn)(void *), void *arg, size_t stride, int n) {
     for (int i = 0; i + 1 < n; i++) { if (made[i]) pthread_join(th[i], NULL); else fn((char *)arg + (size_t)i * stride); }
 }
 
-/* whole file into one buffer: a plain file with read(), a gzip file (magic 1f 8b) through zlib */
+/* a buffer of hundreds of MB is touched once, front to back: with 4 KB pages most of that time is page faults */
+static void big_pages(void *p, size_t n) {
+#ifdef MADV_HUGEPAGE
+    if (n >= (size_t)(32 << 20)) { const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095; if (a < (uintptr_t)p + n) (void)madvise((void *)a, ((uintptr_t)p + n - a) & ~(size_t)4095, MADV_HUGEPAGE); }
+#else
+    (void)p; (void)n;
+#endif
+}
+typedef struct { int fd; char *buf; int64_t beg, end; int64_t err; } rd_job; /* err: 0 whole slice read, -1 I/O error, 1 + bytes read for a short slice */
+static void *rd_work(void *arg) {
+    rd_job *j = (rd_job *)arg;
+    int64_t n = j->beg;
+    while (n < j->end) {
+        const int64_t want = j->end - n > (1 << 30) ? (1 << 30) : j->end - n;
+        const ssize_t got = pread(j->fd, j->buf + n, (size_t)want, (off_t)n);
+        if (got < 0) { j->err = -1; return NULL; }
+        if (got == 0) { j->err = 1 + (n - j->beg); return NULL; }
+        n += got;
+    }
+    return NULL;
+}
+
+/* whole file into one buffer: a plain file with pread() on worker threads, a gzip file (magic 1f 8b) through zlib */
 static int slurp(const char *path, char **out, int64_t *len) {
     int fd = open(path, O_RDONLY);
     if (fd < 0) return PHX_E_IO;
@@ -55,16 +79,15 @@ static int slurp(const char *path, char **out, int64_t *len) {
         const int64_t size = (int64_t)st.st_size;
         char *b = (char *)malloc((size_t)size + 16);
         if (!b) { close(fd); return PHX_E_NOMEM; }
-        b[0] = (char)magic[0]; b[1] = (char)magic[1];
-        int64_t n = 2;
-        while (n < size) {
-            const int64_t want = size - n > (1 << 30) ? (1 << 30) : size - n;
-            const ssize_t got = read(fd, b + n, (size_t)want);
-            if (got < 0) { free(b); close(fd); return PHX_E_IO; }
-            if (got == 0) break;
-            n += got;
-        }
+        big_pages(b, (size_t)size);
+        /* slices of the file read side by side (pread): one thread copies a 500 MB file out of the page cache in 0.1 s */
+        rd_job job[16];
+        const int T = size < (8 << 20) ? 1 : host_threads();
+        for (int t = 0; t < T; t++) { job[t].fd = fd; job[t].buf = b; job[t].beg = size / T * t; job[t].end = t + 1 == T ? size : size / T * (t + 1); job[t].err = 0; }
+        run_threads(rd_work, job, sizeof(rd_job), T);
         close(fd);
+        int64_t n = size;
+        for (int t = T - 1; t >= 0; t--) { if (job[t].err < 0) { free(b); return PHX_E_IO; } if (job[t].err > 0) n = job[t].beg + (job[t].err - 1); } /* a file that shrank: up to the first short slice */
         *out = b; *len = n;
         return PHX_OK;
     }
@@ -172,6 +195,7 @@ int phx_fasta_read(const char *path, phx_fasta **out) {
     phx_fasta *f = (phx_fasta *)calloc(1, sizeof(*f));
     if (!f) { free(b); return PHX_E_NOMEM; }
     f->buf = (char *)malloc((size_t)seq_bytes + 16);
+    if (f->buf) big_pages(f->buf, (size_t)seq_bytes);
     f->names = (char *)malloc((size_t)name_bytes + 1);
     f->seq_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
     f->name_off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
