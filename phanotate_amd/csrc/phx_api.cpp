@@ -222,7 +222,7 @@ void build_dparams(const phx_params *p, DParams *d) {
         else if (stop_is[ci]) cls = CLS_FT;                                 // functions.py:202
         else if (stop_is[rc]) cls = CLS_RT;                                 // functions.py:215
         d->cls_tab[ci] = (uint8_t)(cls | (idx << 3) | (start_idx[rc] >= 0 ? 0x80 : 0));
-        d->atg_tab[ci] = (uint8_t)((ci == atg ? 1 : 0) | (ci == cat ? 2 : 0));
+        d->atg_tab[ci] = (uint8_t)((ci == atg ? 1 : 0) | (ci == cat ? 2 : 0) | (idx << 2)); // bits 2..5: index of the start codon, as in cls_tab
     }
 }
 
@@ -1229,12 +1229,12 @@ int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
             phx_orf &o = out[k];
             o.start = r.start; o.stop = r.stop; o.frame = r.frame;
             o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
-            o.rbs = r.rbs; o.startidx = r.startidx; o.group = (int32_t)rr;
+            o.rbs = rs.rbs; o.startidx = rs.startidx; o.group = (int32_t)rr;
             double S = 0;
             for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = rs.hist[a * 3 + cc]; S += (double)rs.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
             o.S = S;
             o.pstop = rs.pstop;
-            o.weight_rbs = gl.training_rbs[r.rbs] / gl.background_rbs[r.rbs];
+            o.weight_rbs = gl.training_rbs[rs.rbs] / gl.background_rbs[rs.rbs];
             o.weight = dw[(size_t)(G.orf_begin + j)];
         }
     }

@@ -49,20 +49,22 @@ struct DParams { // device copy of phx_params + derived tables
     int32_t n_start;
     double start_w[PHX_MAX_CODONS];
     uint8_t cls_tab[72];  // codon code (c0 | c1<<2 | c2<<4) -> cls byte; entry 64 = no codon (0)
-    uint8_t atg_tab[72];  // bit0: codon == 'atg', bit1: codon == 'cat'; entry 64 = 0
+    uint8_t atg_tab[72];  // bit0: codon == 'atg', bit1: codon == 'cat', bits 2..5: start-codon index (as cls_tab bits 3..6); entry 64 = 0
 };
 
 struct DOrf { // what the scan knows about an ORF: one 16-byte store by k_orf<true>
     int32_t start, stop; // reference Orf.start / Orf.stop (1-based)
     int8_t frame;        // +-1..3
-    uint8_t rbs;         // score_rbs bin
-    int8_t startidx;     // index into params.start or -1
-    uint8_t flags;       // bit0: Orf.start_codon() == 'atg'; bit1: pseudo-start (no start codon: startidx -1).  k_orf<true> leaves rbs, startidx and bit0 to k_orf_stats
+    uint8_t pad[2];
+    uint8_t flags;       // bit1: pseudo-start (no start codon)
     int32_t grp;         // contig-relative group index
 };
-struct DOrfStat { // its statistics: two 16-byte stores by k_orf_stats
+struct DOrfStat { // its statistics and the per-position records of its start codon: two 16-byte stores by k_orf_stats
     uint16_t hist[9];    // GC frame class histogram over the sense codons
-    uint16_t pad[3];
+    uint8_t rbs;         // score_rbs bin
+    int8_t startidx;     // index into params.start or -1 (pseudo-start)
+    uint8_t flags;       // bit0: Orf.start_codon() == 'atg'; bit1: pseudo-start
+    uint8_t pad[3];
     double pstop;        // Orf.p_stop, orfs.py:162-173
 };
 
