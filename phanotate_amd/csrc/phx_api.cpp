@@ -96,7 +96,7 @@ struct phx_ctx {
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
-    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res, b_sord;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -113,6 +113,7 @@ struct phx_ctx {
     // profiling
     bool prof = false;
     uint32_t prof_mask = 0xffffffffu; // stages that are bracketed by events when prof is on
+    int n_simd = 1024; // SIMDs of the device (4 per CU): places of k_sssp_wave
     bool force_global_sssp = false; // development switch: run every contig through the global-memory SSSP kernel
     bool no_wave = false, always_sync = false;
     float stage_ms[PHX_N_STAGES] = {0};
@@ -262,6 +263,8 @@ int64_t cap_of(const DevBuf &b, size_t elem, int64_t reserve) {
 // Batches beyond 4096 contigs keep the gene records in two halves of b_genes: every contig's own place in the first (no shared
 // counter: 20 000 atomics on one address were 0.25 ms), the packed records in the second (k_gene_pack, ~0.03 ms).  Entries per half:
 static inline bool gene_pack(const phx_ctx *c) { return c->n > 4096; }
+// more contigs than k_sssp_wave has places at a time (one wavefront per SIMD): its workgroups take the contigs in the order of k_sssp_order
+static inline bool sssp_ordered(const phx_ctx *c) { return c->n > c->n_simd; }
 static inline int64_t gene_half(const phx_ctx *c) { return (int64_t)(c->b_genes.cap / sizeof(DGene)) / 2; }
 
 void current_caps(const phx_ctx *c, DCaps *k) {
@@ -290,6 +293,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->meta = (DMeta *)c->b_meta.p;
     b->tot = (DTotals *)c->b_tot.p;
     b->lpart = (int64_t *)c->b_lpart.p;
+    b->sord = sssp_ordered(c) ? (int32_t *)c->b_sord.p : nullptr;
     b->res = (DRes *)c->b_res.p;
     current_caps(c, &b->caps);
     b->params = c->d_params;
@@ -376,6 +380,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
+    if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
     if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes)))) return rc;
     if (c->res_cap < (size_t)c->n + 1) {
         if (c->res) (void)hipHostFree(c->res);
@@ -472,6 +477,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->always_sync = getenv("PHX_ALWAYS_SYNC") != nullptr;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_simd = 4 * cus; }
     if (flags & PHX_CREATE_USE_STREAM) { // as given; a null handle is HIP's null stream
         c->stream = (hipStream_t)stream; c->own_stream = false;
         if (!stream) c->graphs_enabled = false; // the legacy stream cannot be captured
@@ -517,7 +523,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -778,6 +784,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
     phxk_wave_plan(&b, (mask >> 6) & 1, c->aux[3]); // bit 4*1+2: 256-bit contigs for the wavefront kernel
+    if (b.sord) phxk_sssp_order(&b, c->aux[3]);
     HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)

@@ -202,6 +202,7 @@ struct DBatch {
     DMeta *meta;
     DTotals *tot;
     DRes *res;          // per contig: status, gene count, first gene record (k_results, the last kernel of a run)
+    int32_t *sord;      // batches beyond one contig per SIMD: contig of workgroup i of k_sssp_wave, most in-edges first (k_sssp_order); else null
     int64_t *lpart;     // k_layout*_a -> _b: per workgroup of 256 contigs the four totals (batches beyond 1024 contigs)
     DCaps caps;
     const DParams *params;
@@ -272,6 +273,7 @@ void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / grou
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, void *stream);
 void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream);
+void phxk_sssp_order(const DBatch *b, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for

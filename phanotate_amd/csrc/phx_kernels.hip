@@ -12,7 +12,8 @@
 //                                                                              363-384 (other_end / o1,o2)
 // edges            k_edges<FILL>, k_edges_scan,             phx_graph.inc      functions.py:334-354, 360-452
 //                  k_edge_weights
-// layout           k_layout1, k_layout2                     phx_layout.inc     (offsets, integer class and solver per contig)
+// layout           k_layout1, k_layout2, k_sssp_order,      phx_layout.inc     (offsets, integer class and solver per contig; launch order of the
+//                  k_gene_pack, k_results                                      solver and gene slots for large batches; result records)
 // shortest path    k_wave_plan + k_sssp_wave<2> (wavefront  phx_sssp_wave.inc  fastpathz (phanotate.py:56-64), exact NL x 64-bit
 //                  / contig)
 //                  k_sssp_lds<NL> (workgroup / contig),     phx_sssp.inc       integers; path -> genes phanotate.py:65-76,
@@ -207,6 +208,8 @@ void phxk_layout2(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_layout2_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_layout2_b, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
 }
+
+void phxk_sssp_order(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_sssp_order, dim3(1), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 
 int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
