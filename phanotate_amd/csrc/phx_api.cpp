@@ -83,7 +83,7 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
@@ -302,7 +302,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->cls = (uint8_t *)c->b_cls.p;
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
-    b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p;
+    b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p; b->iprev = (int32_t *)c->b_iprev.p;
     b->cpre = (uint32_t *)c->b_cpre.p; b->bpre = (uint32_t *)c->b_bpre.p;
     b->bridge = (DBridge *)c->b_bridge.p;
     if (c->has_trna) { b->tnode = (const DTNode *)c->b_tnode.p; b->tedge = (const DTEdge *)c->b_tedge.p; b->tnid = (int32_t *)c->b_tnid.p; b->tbits = (uint64_t *)c->b_tbits.p; }
@@ -396,6 +396,7 @@ int ensure_position_buffers(phx_ctx *c) {
         if ((rc = ensure(c, c->b_bpre, (3 * W / PHX_PRE_G + (size_t)c->n + 2) * 16))) return rc;
     }
     if ((rc = ensure(c, c->b_item, (size_t)(c->tot_items + 8) * 8))) return rc;
+    if ((rc = ensure(c, c->b_iprev, (size_t)(c->tot_items + 8) * 4))) return rc;
     if ((rc = ensure(c, c->b_bridge, (size_t)(c->tot_bridge + 8) * sizeof(DBridge)))) return rc;
     return PHX_OK;
 }
@@ -522,7 +523,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
