@@ -753,7 +753,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s)); // the offsets stand; the capacities are now sufficient
     }
     fill_batch(c, &b);
-    HIPCHK(c, hipMemsetAsync(c->b_cbits.p, 0, (size_t)(b.caps.cb + 8) * 8, s));
     { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
     // nodes (coverage, ranks, records, order) beside the ORF statistics: both only read what k_orf<true> wrote
     HIPCHK(c, hipEventRecord(c->ev_fork_nodes, s));

@@ -213,7 +213,7 @@ struct DBatch {
     uint16_t *rbs;
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
-    uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); zeroed every run
+    uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); written whole by k_node_order
     uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     int32_t *iprev;     // per (strand, frame, word): the last item in front of it whose word holds a stop codon, -1: none (k_orf<false> -> k_orf<true>)
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
