@@ -44,7 +44,7 @@ def algorithmic_bytes(sz):
 
 STAGE_KERNEL = {"sssp": "k_sssp_wave<2>", "features": "k_features", "edges_fill": "k_edges<true>", "edges_count": "k_edges<false>",
                 "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true>", "orf_count": "k_orf<false>", "nodes": "k_node_build", "score": "k_score",
-                "edge_weights": "k_edge_weights", "inorder": "k_inorder<2>"}
+                "inorder": "k_inorder<2>"}
 
 
 def pmc_traffic(stage, contigs, length):

@@ -219,7 +219,8 @@ int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int3
 int phx_set_profiling(phx_ctx *ctx, int on);
 /* The same for a subset of the stages (bit k = stage k; 0 switches profiling off): two events per run instead of two per stage. */
 int phx_set_profiling_stages(phx_ctx *ctx, uint32_t stage_mask);
-/* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k). */
+/* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k).  (Stage "edge_weights" keeps its
+   index but stays at zero: the overlap weights are evaluated inside the edge fill.) */
 int phx_get_stage_ms(phx_ctx *ctx, float *ms /* [PHX_N_STAGES] */, int32_t *launches /* [PHX_N_STAGES] */, int reset);
 const char *phx_stage_name(int k);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */

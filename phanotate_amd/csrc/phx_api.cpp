@@ -766,7 +766,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipGetLastError());
     mask = c->last_mask;
     for (int k = 0; k < 4; k++) lds[k] = c->last_lds[k];
-    int64_t n_edges = b.caps.edge;
     if (learn) { // sync #2: edge total, widest integer class, solver classes
         { StageTimer t(c, ST_COPY); HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s)); }
         HIPCHK(c, hipStreamSynchronize(s));
@@ -777,7 +776,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s));
         mask = ht->class_mask;
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
-        n_edges = ht->edge;
     }
     fill_batch(c, &b);
     // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
@@ -789,7 +787,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
         { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
-        { StageTimer t(c, ST_EDGE_WEIGHTS); phxk_edge_weights(&b, n_edges, s); }
     }
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the

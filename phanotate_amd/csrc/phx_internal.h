@@ -248,7 +248,7 @@ struct DBatch {
     const uint32_t *ekey; // optional rank of every edge in the caller's edge order (phx_solve); else the reference's node insertion order is used
     uint8_t *tie;        // scratch of k_inorder (bump-allocated through DTotals.tie_need)
     int64_t tie_cap;
-    int32_t defer_overlap; // 1: k_edges<true> records overlap edges, k_edge_weights evaluates them (needs node ids < 2^21)
+    int32_t defer_overlap; // 1: k_edges<true> queues the overlap edges of a workgroup and evaluates their weights after the neighbour scan (needs node ids < 2^21)
     // output
     int32_t *path;
     DGene *genes;
@@ -273,7 +273,6 @@ void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, void *stream);
-void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream);
 void phxk_sssp_order(const DBatch *b, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);

@@ -10,8 +10,7 @@
 // ORF weight       k_score                                  phx_orf.inc        functions.py:254-257,281-284,300-301, orfs.py:122-127
 // nodes            k_node_cov/_rank/_build/_attr            phx_graph.inc      functions.py:311-318 (nodes), 320-333 (coverage),
 //                                                                              363-384 (other_end / o1,o2)
-// edges            k_edges<FILL>, k_edges_scan,             phx_graph.inc      functions.py:334-354, 360-452
-//                  k_edge_weights
+// edges            k_edges<FILL>, k_edges_scan              phx_graph.inc      functions.py:334-354, 360-452
 // layout           k_layout1, k_layout2, k_sssp_order,      phx_layout.inc     (offsets, integer class and solver per contig; launch order of the
 //                  k_gene_pack, k_results                                      solver and gene slots for large batches; result records)
 // shortest path    k_wave_plan + k_sssp_wave<2> (wavefront  phx_sssp_wave.inc  fastpathz (phanotate.py:56-64), exact NL x 64-bit
@@ -157,11 +156,6 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
-// the overlap weights k_edges<true> left pending
-void phxk_edge_weights(const DBatch *b, int64_t n_edges, void *stream) {
-    if (b->defer_overlap && n_edges > 0)
-        hipLaunchKernelGGL(k_edge_weights, dim3((unsigned)((n_edges + EW_T * EW_PER - 1) / (EW_T * EW_PER))), dim3(EW_T), 0, (hipStream_t)stream, b->esrc, b->ew, (const DTotals *)b->tot);
-}
 // phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
     phxk_sssp(b, nl, 0, 0, stream);
