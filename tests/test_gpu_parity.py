@@ -537,6 +537,20 @@ def test_large_contig_beyond_lds_parent_table(pa, oracle):
     ann.close()
 
 
+def test_contig_beyond_two_million_bases(pa, oracle):
+    """2.2 Mbp in one contig: node ids no longer fit the 21 bits of the queued overlap-edge record, so k_edges<true> evaluates the
+    overlap weights in place (DBatch.defer_overlap = 0); 1430 feature tiles, 11 500 bitmap words per frame, ~94 k nodes solved
+    by the global-memory kernel.  Everything must still equal the oracle."""
+    seq = pa.synth_contig(4242, 2200000)
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    o = oracle.run(seq)
+    assert status == 0 and o["status"] == 0
+    assert ann.globals(0).n_node > 80000
+    check_contig(ann, 0, seq, o, genes, status)
+    ann.close()
+
+
 @pytest.mark.parametrize("ncodons,p_gtg,expect", [(3000, 0.12, "wave"), (3500, 0.20, "wave"), (5500, 0.27, "handed_back"), (4000, 0.45, "dense")])
 def test_gc_rich_long_orf_wavefront_kernel_paths(pa, oracle, ncodons, p_gtg, expect):
     """A 9-12 kb reading frame in a GC-rich contig: p_stop is small, so the path sums still fit 128 bits and the contig
