@@ -83,7 +83,7 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_cls, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
@@ -299,7 +299,6 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
     b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
-    b->cls = (uint8_t *)c->b_cls.p;
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p; b->iprev = (int32_t *)c->b_iprev.p;
@@ -372,7 +371,6 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
 int ensure_position_buffers(phx_ctx *c) {
     const size_t T = (size_t)c->totalL + 64;
     int rc;
-    if ((rc = ensure(c, c->b_cls, T))) return rc;
     if ((rc = ensure(c, c->b_rbs, T * 2))) return rc;
     if ((rc = ensure(c, c->b_nbits, (size_t)(c->tot_nbits + 8) * 8))) return rc;
     if ((rc = ensure(c, c->b_nbase, (size_t)(c->tot_nbits / 3 + 8) * 4))) return rc;
@@ -523,7 +521,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_cls, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
+    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1172,7 +1170,32 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
 int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, uint8_t *binF, uint8_t *binR) {
     TAP_PRE(c, contig);
     const size_t L = (size_t)m.L;
-    if (cls) HIPCHK(c, hipMemcpy(cls, (uint8_t *)c->b_cls.p + m.off, L, hipMemcpyDeviceToHost));
+    if (cls) { // the device keeps the codon classes as four bitmaps and the start-codon index in the RBS word; the "rev_comp(codon) is a
+               // start" bit of a forward start codon (no kernel reads it) comes from the letters
+        const size_t nw = (size_t)m.nw;
+        std::vector<uint64_t> bits((size_t)4 * 3 * nw);
+        std::vector<uint16_t> r(L);
+        std::vector<uint8_t> asc(L);
+        if (nw) HIPCHK(c, hipMemcpy(bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, bits.size() * 8, hipMemcpyDeviceToHost));
+        if (L) HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));
+        if (L) HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
+        DParams dp;
+        build_dparams(&c->params, &dp);
+        auto code = [](uint8_t ch) -> int { switch (ch | 0x20) { case 'a': return 0; case 'c': return 1; case 't': return 2; case 'g': return 3; default: return -1; } };
+        for (size_t p = 0; p < L; p++) {
+            uint8_t v = 0;
+            if (p + 3 <= L) {
+                const size_t f = p % 3, k = p / 3;
+                auto bit = [&](int id) { return (int)((bits[((size_t)id * 3 + f) * nw + (k >> 6)] >> (k & 63)) & 1ull); };
+                const int cl = bit(0) ? CLS_FS : bit(1) ? CLS_RS : bit(2) ? CLS_FT : bit(3) ? CLS_RT : CLS_NONE;
+                v = (uint8_t)cl;
+                if (cl == CLS_FS || cl == CLS_RS) v |= (uint8_t)((r[p] >> 12) << 3);
+                const int c0 = code(asc[p]), c1 = code(asc[p + 1]), c2 = code(asc[p + 2]);
+                if (c0 >= 0 && c1 >= 0 && c2 >= 0) v |= (uint8_t)(dp.cls_tab[c0 | (c1 << 2) | (c2 << 4)] & 0x80u);
+            }
+            cls[p] = v;
+        }
+    }
     if (gcc) { // the device keeps the GC-frame classes bit-sliced: 9 forward + 9 reverse class bitmaps per frame
         const size_t nw = (size_t)m.nw;
         std::vector<uint64_t> bits((size_t)PHX_BITMAP_WORDS_PER_NW * nw);

@@ -209,7 +209,6 @@ struct DBatch {
     const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;
     // per position
     const uint8_t *ascii;
-    uint8_t *cls;
     uint16_t *rbs;
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
