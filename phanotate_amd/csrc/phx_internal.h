@@ -1,11 +1,11 @@
 // phx_internal.h — device/host shared layouts of libphx (not part of the public ABI).
 //
 // Data layout in HBM (one batch = n contigs, concatenated):
-//   per position (index = meta.off + p, p 0-based):  ascii u8, cls u8, gcc u8, cnt u8, rbs u16,
-//       linkF u32, linkR u32, cov u8          (linkF/linkR/cov are indexed by 1-based position - 1)
+//   per position (index = meta.off + p, p 0-based):  ascii u8, rbs u16 (RBS bins, 'atg' flags, start-codon index); everything else
+//       that is a predicate of a position or codon lives in bitmaps (bits, nbits: DESIGN.md §3)
 //   per ORF   (index = meta.orf_off + k):  DOrf head (16 B), DOrfStat (32 B), weight f64, start-node id i32 — four arrays, each
 //       written whole by one kernel (k_orf<true>, k_orf_stats, k_score, k_node_build)
-//   per group (index = meta.grp_off + g, g in reference insertion order):  DGrp (24 B)
+//   per group (index = meta.grp_off + g, device order = (strand, frame, codon); DGrp.evkey = reference insertion order):  DGrp (32 B)
 //   per node  (index = meta.node_off + v, v sorted by position; source = V-2, target = V-1):
 //       DNode {pos i32, info i32, link u32, other i32}, no f64, in_off u32 (+1), dist NL x u64, parent i32
 //   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32, ew f64
@@ -29,7 +29,7 @@
 #define CLS_RS 2 // rev_comp(codon) in start_codons
 #define CLS_FT 3 // codon in stop_codons
 #define CLS_RT 4 // rev_comp(codon) in stop_codons
-// cls byte: bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
+// cls byte (DParams.cls_tab, the cls tap; no per-position array on the device): bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
 
 // node link word: bits 30-31 kind, bits 0-29 index
 #define LINK_NONE 0u
