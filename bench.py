@@ -47,10 +47,10 @@ STAGE_KERNEL = {"sssp": "k_sssp_wave<2>", "features": "k_features", "edges_fill"
                 "inorder": "k_inorder<2>"}
 
 
-def pmc_traffic(stage, contigs, length):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC run (profiles/traffic.json: separate
-    FETCH_SIZE / WRITE_SIZE passes of `bench.py`, gfx950 correction applied by tools/pmc_summary.py).  It is NOT measured in
-    this process (counters need rocprofv3); only meaningful for the workload it was collected on."""
+def pmc_traffic_committed(stage, contigs, length):
+    """Fallback: HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC run (profiles/traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE passes of `bench.py`, gfx950 correction applied by tools/pmc_summary.py).  Only meaningful for the
+    workload it was collected on."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if contigs != 1000 or length != 50000 or stage not in STAGE_KERNEL or not os.path.exists(path):
         return None
@@ -62,6 +62,42 @@ def pmc_traffic(stage, contigs, length):
         if STAGE_KERNEL[stage] in k and "hbm_bytes" in v:
             return int(v["hbm_bytes"])
     return None
+
+
+def pmc_traffic_live(contigs, length, device):
+    """HBM bytes per launch of every kernel of one step, measured now: two rocprofv3 passes (`--pmc FETCH_SIZE`, `--pmc
+    WRITE_SIZE`, kernel trace only — the counters do not fit one pass) over a one-step run of this script on the same workload.
+    FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte read requests as 64 bytes (MI355X_MICROARCH.md, HBM
+    section), so bytes = (2 FETCH + WRITE) * 1024 — calibrated for streaming reads, applied to scattered ones as well.
+    Returns ({kernel name: bytes per launch}, total per step) or None (no rocprofv3, or this process is itself being profiled)."""
+    import csv
+    import shutil
+
+    exe = shutil.which("rocprofv3")
+    if not exe or os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    per = {}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            env = dict(os.environ, TMPDIR=td, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(td, ctr)
+                cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                       "--steps", "1", "--warmup", "0", "--no-extras", "--no-pipeline", "--contigs", str(contigs), "--length", str(length)]
+                r = subprocess.run(cmd, cwd=td, env=env, capture_output=True, text=True, timeout=900)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return None
+                last = {}
+                for row in csv.DictReader(open(files[0])):
+                    if row["Counter_Name"] == ctr and "rocclr" not in row["Kernel_Name"]:
+                        last[row["Kernel_Name"]] = float(row["Counter_Value"])  # the last dispatch of every kernel: a steady-state run
+                for k, v in last.items():
+                    per.setdefault(k, {})[ctr] = v
+    except Exception:
+        return None
+    out = {k: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0) for k, v in per.items() if k.startswith("k_") or "k_" in k}
+    return (out, sum(out.values())) if out else None
 
 
 def read_golden_fasta(case):
@@ -165,7 +201,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the single-contig lines, the CPU baselines and the CLI run")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two_batches_in_flight lines (profiling passes: every launch then belongs to the one-batch-at-a-time regions)")
     ap.add_argument("--smoke-single-device", action="store_true",
-                    help="N > 1 ranks on ONE GPU over gloo: exercises the sharded code path (partition, per-rank shards, flat gather) where no multi-GPU node is at hand; its numbers mean nothing")
+                    help="N > 1 ranks on ONE GPU: the sharded code path (partition, per-rank shards, gather of the flat arrays over the group's gloo half) where no multi-GPU node is at hand; only the barrier / reductions differ from a multi-GPU launch (gloo instead of RCCL); its numbers mean nothing")
+    ap.add_argument("--force-dist", action="store_true", help="bring the process group up even with one rank (exercises the RCCL + gloo group of a multi-GPU launch on a 1-GPU box)")
+    ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged (status, offsets, genes) of the host-to-host region to this .npz (tests)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic (use profiles/traffic.json)")
     args = ap.parse_args()
 
     import numpy as np
@@ -190,15 +229,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     red_dev = "cuda"
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or args.force_dist:
+        # one group, two backends: barrier / reductions of CUDA tensors over RCCL, the result gather (host arrays) over gloo
+        from phanotate_amd.shard import init_group
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.smoke_single_device:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            red_dev = "cpu"
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist, red_dev = init_group(rank, world, device=local_rank, single_device=args.smoke_single_device)
 
     L_ = args.length
     if args.workload == "synthetic":
@@ -207,7 +243,7 @@ def main():
         # partition only needs the lengths, so every rank derives it without generating the other ranks' contigs)
         mine = list(range(n_total)) if world == 1 else partition([L_] * n_total, world)[rank]
         seqs = [pa.synth_contig(i, L_) for i in mine]
-        wl = ("batch of %d synthetic %d bp phage contigs on one GPU, resident in HBM (BASELINE config 4)" % (n_total, L_)) if world == 1 else (
+        wl = ("batch of %d synthetic %d bp phage contigs on one GPU, resident in HBM (%s)" % (n_total, L_, "BASELINE config 4" if n_total == 1000 else "BASELINE config 5's job on one GPU: the N = 1 base of the strong-scaling curve" if n_total == 10000 else "non-standard size")) if world == 1 else (
             "%d synthetic %d bp phage contigs (seeds 0..%d) sharded per contig over %d GPUs by shard.partition, %d on rank 0 (BASELINE config 5)" % (n_total, L_, n_total - 1, world, len(mine)))
     else:
         if world != 1:
@@ -225,7 +261,10 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if red_dev == "cuda":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
         # (the context's stream is idle between calls: phx_run / phx_download block until their results are on the host)
 
@@ -314,6 +353,20 @@ def main():
 
     if rank == 0:
         st_all, offs_all, genes_all = merged
+        if args.dump_merged:
+            np.savez(args.dump_merged, status=st_all, offsets=offs_all, genes=genes_all)
+        # roofline.traffic: HBM bytes per launch from the PMC counters, measured now when rocprofv3 is at hand (two extra one-step
+        # runs of this script under `rocprofv3 --pmc`, kernel trace only), else from the committed passes of the same command
+        live = None
+        if world == 1 and args.workload == "synthetic" and not args.no_extras and not args.no_traffic:
+            live = pmc_traffic_live(len(seqs), L_, local_rank)
+
+        def traffic_of(stage):
+            if live is not None:
+                hits = [v for k, v in live[0].items() if STAGE_KERNEL.get(stage, "\0") in k]
+                return hits[0] if hits else None
+            return pmc_traffic_committed(stage, len(seqs), L_) if args.workload == "synthetic" else None
+
         dom_ms = dom_total / max(dom_n, 1)
         balgo = algorithmic_bytes(sz)
         achieved = balgo / (dom_ms * 1e-3) / 1e9
@@ -327,7 +380,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
+            "scaling": "weak" if world == 1 and n_total != 10000 else "strong",
             "vs_baseline": None,
             "dtype": "u8/int128 (fp64 edge weights)",
             "data": ("synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)") + (" [SMOKE: all ranks on one GPU, gloo]" if args.smoke_single_device else ""),
@@ -363,8 +416,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": pmc_traffic(dom, len(seqs), L_) if args.workload == "synthetic" else None,
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not measured in this process)",
+                "traffic": traffic_of(dom),
+                "traffic_source": ("measured in this run: two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) of a one-step run of this command; bytes = (2 FETCH + WRITE) KiB, the guide's gfx950 correction for streaming reads" if live is not None
+                                   else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; rocprofv3 not available to this process or --no-traffic)"),
+                "traffic_step_total": None if live is None else live[1],
                 "algorithmic_bytes_per_launch": int(balgo),
                 "avg_launch_ms": round(dom_ms, 4),
                 "step_frac": round(step_achieved / HBM_PEAK_GBS, 6),
@@ -372,7 +427,7 @@ def main():
                 "step_kernel_ms": round(kernel_ms_per_step, 4),
                 "step_frac_is": "SURVEY.md §8(d): sum of algorithmic bytes / sum of kernel time of one step (all stages, HIP events), / peak",
                 "runner_up": {"kernel": second, "avg_launch_ms": round(sec_total / max(sec_n, 1), 4), "frac": round(balgo / (sec_total / max(sec_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                              "traffic": pmc_traffic(second, len(seqs), L_) if args.workload == "synthetic" else None,
+                              "traffic": traffic_of(second),
                               "why": "k_features and k_sssp_wave<2> take 0.50-0.52 ms each: which of the two is longer changes from run to run; both are measured with HIP events in the timed region"},
             },
             "stage_ms_per_step": {k: round(v[0] / 3, 4) for k, v in stages_all.items() if v[1] > 0},
@@ -399,6 +454,29 @@ def main():
                                    "int_limbs": int(gl.n_limbs), "solver_kernel": int(gl.sssp_kernel), "status": int(st1)}
                     a1.close()
                 out["single_contig"] = single
+            if args.workload == "synthetic" and n_total == 1000 and L_ == 50000:
+                # BASELINE config 5's whole job (seeds 0..9999) on this one GPU: the N = 1 point of the strong-scaling curve
+                # whose N > 1 points `bench.py --gpus N` measures (the same contigs, sharded by shard.partition)
+                big = [pa.synth_contig(i, L_) for i in range(10000)]
+                a5 = pa.Annotator(device=local_rank)
+                st5, offs5, g5 = a5.annotate_flat(big)
+                for _ in range(2):
+                    a5.run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    a5.run()
+                t5 = (time.perf_counter() - t0) / 3
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    a5.annotate_flat(big)
+                t5h = (time.perf_counter() - t0) / 2
+                out["strong_scaling_base"] = {"contigs": 10000, "n_gpus": 1, "value": round(len(big) * L_ / t5 / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5 * 1e3, 3),
+                                              "host_to_host": {"value": round(len(big) * L_ / t5h / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5h * 1e3, 3)},
+                                              "genes_called_total": int(len(g5)), "contigs_with_error_status": int((st5 < 0).sum()),
+                                              "what": "config 5's 10 000 contigs as one batch resident on one GPU (3 timed runs; = `bench.py --gpus 1 --contigs 10000`): divide the N > 1 lines' value by this for strong-scaling efficiency"}
+                a5.close()
+                del big
             if not args.no_cpu:
                 one, allc = cpu_baselines(seqs, L_, args.cpu_contigs if args.workload == "synthetic" else 1, args.cpu_per_core)
                 out["cpu_baseline"] = one

@@ -44,6 +44,7 @@ extern "C" {
 #define PHX_S_OK 0
 #define PHX_S_BADLETTER (-2) /* letter outside acgtnryswkmbvdh [KeyError, functions.py:20-24] */
 #define PHX_S_TOOSHORT (-3)  /* L < 6 [UnboundLocalError/KeyError in GCframe.get, gc_frame_plot.py:53-69] */
+#define PHX_S_BADTRNA (-4)   /* phx_set_trnas: a hit of this contig has an end outside 1..L (no node can be placed there) */
 #define PHX_S_PARALLEL (-6)  /* a bridge edge duplicates a connect edge [ValueError, graphs.py:74] */
 #define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit) */
 #define PHX_S_LONGORF (-8)   /* an ORF of more than 65535 codons (196 kb without an in-frame stop, e.g. a scaffold's N run): the per-ORF
@@ -154,6 +155,13 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
  * so that work of this ctx is ordered after whatever the caller enqueued there before (e.g. the kernels that produce a
  * buffer handed to phx_attach).  On the null stream the run is enqueued kernel by kernel (HIP cannot capture it into a graph). */
 #define PHX_CREATE_USE_STREAM 1u
+/* Development / test switches (results are the same with any of them): enqueue every run kernel by kernel instead of replaying a
+ * captured HIP graph; size the buffers between kernels on every run (two host round trips) instead of only on the first; solve every
+ * contig with the global-memory shortest-path kernel; keep contigs off the wavefront-per-contig kernel. */
+#define PHX_CREATE_NO_GRAPH 2u
+#define PHX_CREATE_SIZE_EVERY_RUN 4u
+#define PHX_CREATE_SOLVER_GLOBAL 8u
+#define PHX_CREATE_SOLVER_NO_WAVE 16u
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 
@@ -169,7 +177,7 @@ int phx_attach(phx_ctx *ctx, int32_t n, const void *d_ascii, const int64_t *offs
 /* tRNA masking (functions.add_trnas, functions.py:457-509): the hits of an external tRNA finder for the contigs of the batch just
  * uploaded / attached, as the reference holds them in `trnas`: hits of contig i are (start[k], stop[k]) for k in
  * [offsets[i], offsets[i+1]); start < stop for a hit on the forward strand, start > stop (the pair reversed) for a complement hit;
- * 1-based, inside the contig.  The device then adds the tRNA nodes (frame +-4), their edges of weight -20 and the connect rules
+ * 1-based, inside the contig (a contig with a hit outside 1..L gets status PHX_S_BADTRNA; the batch goes on).  The device then adds the tRNA nodes (frame +-4), their edges of weight -20 and the connect rules
  * of functions.py:388-399.  Call after phx_upload / phx_attach and before phx_run; a new upload forgets the hits.  Not calling
  * it (or offsets == NULL) is "no tRNA finder installed" (functions.py:493-495).  Running the finders is the caller's business
  * (phanotate_amd/trna.py does what functions.py:457-491 does). */

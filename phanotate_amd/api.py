@@ -61,14 +61,19 @@ class Annotator:
     0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
     context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
-    def __init__(self, params=None, device=0, stream=None):
+    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16}  # PHX_CREATE_* development / test switches
+
+    def __init__(self, params=None, device=0, stream=None, flags=()):
         self.L = _lib.lib()
         self.params = params or make_params()
         h = C.c_void_p()
+        fl = 0
+        for f in flags:
+            fl |= self.FLAGS[f]
         if stream is None:
-            rc = self.L.phx_create_ex(C.byref(self.params), int(device), None, 0, C.byref(h))
+            rc = self.L.phx_create_ex(C.byref(self.params), int(device), None, fl, C.byref(h))
         else:
-            rc = self.L.phx_create_ex(C.byref(self.params), int(device), C.c_void_p(int(stream)), 1, C.byref(h))
+            rc = self.L.phx_create_ex(C.byref(self.params), int(device), C.c_void_p(int(stream)), 1 | fl, C.byref(h))
         if rc:
             raise PhxError(rc, "%s (%s)" % (self.L.phx_strerror(rc).decode(), self.L.phx_last_error(None).decode()))
         self.h = h

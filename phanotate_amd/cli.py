@@ -14,7 +14,7 @@ from . import __version__
 from .api import Annotator, make_params
 from .writers import FORMATS, write
 
-STATUS_TEXT = {-2: "letter outside the nucleotide alphabet (the reference raises KeyError)", -3: "contig shorter than 6 bases",
+STATUS_TEXT = {-2: "letter outside the nucleotide alphabet (the reference raises KeyError)", -3: "contig shorter than 6 bases", -4: "a tRNA hit lies outside the contig",
                -6: "parallel edges are forbidden (graphs.py:74)", -7: "integer overflow in path sums", -8: "an open reading frame of more than 65535 codons", -9: "negative cycle"}
 
 
@@ -37,6 +37,7 @@ def get_args(argv=None):
     p.add_argument("-V", "--version", action="version", version=__version__)
     p.add_argument("--device", type=int, default=None, help="GPU ordinal [LOCAL_RANK or 0]")
     p.add_argument("--batch-bases", type=int, default=400_000_000, help="bases per GPU batch [4e8]")
+    p.add_argument("--single-device-ranks", action="store_true", help=argparse.SUPPRESS)  # tests: every rank of a sharded launch on GPU `--device` (gloo-only group)
     return p.parse_args(argv)
 
 
@@ -113,10 +114,23 @@ def main(argv=None):
             ctx_box["err"] = e
 
     ctx_thread = threading.Thread(target=make_context, daemon=True)
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1:  # (sharded runs bring torch.distributed up first, on this thread)
+    threaded = int(os.environ.get("WORLD_SIZE", "1")) == 1  # (sharded runs bring torch.distributed up first, on this thread)
+    if threaded:
         ctx_thread.start()
-    fa = Fasta(args.infile)
+
+    def drop_context():  # every early exit: never leave the interpreter while the worker is still inside hipInit / phx_create
+        if threaded:
+            ctx_thread.join()
+        if "ann" in ctx_box:
+            ctx_box.pop("ann").close()
+
+    try:
+        fa = Fasta(args.infile)
+    except BaseException:
+        drop_context()
+        raise
     if not len(fa) or not int(fa.lens.sum()):
+        drop_context()
         sys.stdout.write("Error: no sequences found in infile\n")  # phanotate.py:33-35
         return 0
     t_parsed = time.perf_counter()
@@ -124,11 +138,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        from .shard import init_group
 
-        torch.cuda.set_device(device)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist, _ = init_group(rank, world, device=device, single_device=args.single_device_ranks)
     if world == 1:
         ctx_thread.join()
     else:
@@ -140,7 +152,7 @@ def main(argv=None):
     t_parts = {"upload_s": 0.0, "run_s": 0.0, "download_s": 0.0, "batches": 0}
     import shutil
 
-    from .trna import find_trnas
+    from .trna import find_trnas_many
 
     have_finder = bool(shutil.which("aragorn") or shutil.which("tRNAscan-SE"))
 
@@ -149,13 +161,14 @@ def main(argv=None):
             for _ in idx:
                 sys.stderr.write("Warning: tRNAscan or Aragorn were not found, proceding without tRNA masking.\n")
             return None
-        return [find_trnas(fa.seq(int(i))) or [] for i in idx]
+        return find_trnas_many(fa.seq(int(i)) for i in idx)  # the finder processes of a batch run side by side
 
     if args.dump:  # the reference dumps the first contig's edges and exits (phanotate.py:58-61)
         ann.upload_raw(fa.ptrs[:1], fa.lens[:1], fa)
         ann.set_trnas(trnas_of([0]))
         ann.run()
         dump_edges(args.outfile, ann, 0, fa.seq(0), args.start_codons)
+        ann.close()
         return 0
 
     n_total = len(fa)

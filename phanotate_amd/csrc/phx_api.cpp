@@ -424,6 +424,7 @@ const char *phx_strerror(int code) {
     case PHX_S_BADLETTER: return "letter outside the IUPAC nucleotide alphabet";
     case PHX_S_TOOSHORT: return "contig shorter than 6 bases";
     case PHX_S_PARALLEL: return "bridge edge duplicates a connect edge";
+    case PHX_S_BADTRNA: return "a tRNA hit lies outside the contig";
     case PHX_S_OVERFLOW: return "integer path sums overflow";
     case PHX_S_LONGORF: return "an open reading frame of more than 65535 codons";
     case PHX_S_NEGCYCLE: return "relaxation did not converge";
@@ -456,7 +457,7 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~PHX_CREATE_USE_STREAM) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -469,11 +470,12 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     phx_ctx *c = new phx_ctx();
     c->device = device;
     c->params = *params;
-    // development switches, read once per context (tools/, not used by the tests): solver kernel selection, no HIP graph, sizing mode every run
-    c->force_global_sssp = getenv("PHX_FORCE_GLOBAL_SSSP") != nullptr;
-    c->no_wave = getenv("PHX_SSSP_NOWAVE") != nullptr;
-    c->graphs_enabled = getenv("PHX_NO_GRAPH") == nullptr;
-    c->always_sync = getenv("PHX_ALWAYS_SYNC") != nullptr;
+    // what a context does is a matter of its arguments alone (no environment variable changes it): solver kernel selection, no HIP
+    // graph, sizing mode every run are flags of phx_create_ex, used by tools/ and the tests that force a solver kernel
+    c->force_global_sssp = (flags & PHX_CREATE_SOLVER_GLOBAL) != 0;
+    c->no_wave = (flags & PHX_CREATE_SOLVER_NO_WAVE) != 0;
+    c->graphs_enabled = (flags & PHX_CREATE_NO_GRAPH) == 0;
+    c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_simd = 4 * cus; }
@@ -622,7 +624,7 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
     if (c->in_flight) (void)settle(c);
     c->ran = false; c->graph_valid = false; c->meta0_dirty = true; c->runs_on_layout = 0;
     c->has_trna = false; c->h_tnode.clear();
-    for (DMeta &m : c->meta) { m.n_tnode = 0; m.n_tedge = 0; m.tn_off = 0; m.te_off = 0; if (m.status == PHX_S_PARALLEL) m.status = 0; }
+    for (DMeta &m : c->meta) { m.n_tnode = 0; m.n_tedge = 0; m.tn_off = 0; m.te_off = 0; if (m.status == PHX_S_PARALLEL || m.status == PHX_S_BADTRNA) m.status = 0; }
     if (!offsets) return PHX_OK; // no tRNA finder: the graph is built without add_trnas' part (functions.py:493-495)
     const int n = c->n;
     if (offsets[0] != 0) return PHX_E_ARG;
@@ -642,16 +644,18 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
             tn.push_back(DTNode{pos, info, -1, (int32_t)(tn.size() - n0)});
             return (int32_t)(tn.size() - 1 - n0);
         };
-        bool parallel = false;
+        bool parallel = false, outside = false;
         for (int64_t k = offsets[i]; k < offsets[i + 1]; k++) {
             const int32_t a = start[k], z = stop[k];
             int32_t s, t;
+            // both nodes of a hit must sit on a base of the contig (the node bitmaps cover 1..L); a hit that does not — a finder run
+            // with a circular topology, a truncated parse — fails this contig, not the batch
             if (a < z) { // functions.py:499-503
-                if (a < 1 || z - 2 < 1 || z - 2 > m.L) return PHX_E_ARG;
+                if (a < 1 || a > m.L || z - 2 < 1 || z - 2 > m.L) { outside = true; break; }
                 s = node(0, 4, a); t = node(1, 4, z - 2);
                 set_other(z - 2, a); set_other(a, z - 2);
             } else { // functions.py:504-508
-                if (z < 1 || a - 2 < 1 || a - 2 > m.L || z > m.L) return PHX_E_ARG;
+                if (z < 1 || z > m.L || a - 2 < 1 || a - 2 > m.L) { outside = true; break; }
                 s = node(1, -4, z); t = node(0, -4, a - 2);
                 set_other(a - 2, z); set_other(z, a - 2);
             }
@@ -660,7 +664,8 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
         }
         for (size_t k = n0; k < tn.size(); k++) for (auto &o : other) if (o.first == tn[k].pos) tn[k].other = o.second;
         m.n_tnode = (int32_t)(tn.size() - n0); m.n_tedge = (int32_t)(te.size() - e0);
-        if (parallel) { m.status = PHX_S_PARALLEL; m.n_tedge = -1; } // the reference raises (graphs.py:74); marked for run_once
+        if (outside) { tn.resize(n0); te.resize(e0); m.n_tnode = 0; m.n_tedge = -1; m.status = PHX_S_BADTRNA; }
+        else if (parallel) { m.status = PHX_S_PARALLEL; m.n_tedge = -1; } // the reference raises (graphs.py:74); marked for run_once
     }
     if (tn.empty()) return PHX_OK; // finders ran and found nothing: same graph as without
     int rc;
@@ -873,7 +878,7 @@ int launch_once(phx_ctx *c, bool learn) {
             m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
             m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
             m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
-            if (k.status == PHX_S_PARALLEL && k.n_tedge < 0) { m.status = PHX_S_PARALLEL; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74)
+            if ((k.status == PHX_S_PARALLEL || k.status == PHX_S_BADTRNA) && k.n_tedge < 0) { m.status = k.status; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74); a hit outside the contig
         }
         HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipStreamSynchronize(s));

@@ -74,8 +74,10 @@ static int slurp(const char *path, char **out, int64_t *len) {
     if (fd < 0) return PHX_E_IO;
     unsigned char magic[2] = {0, 0};
     struct stat st;
-    const ssize_t got2 = read(fd, magic, 2);
-    if (got2 == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+    /* the magic is looked at with pread() and only in a regular file: a pipe, /dev/stdin or <(zcat x.gz) must reach zlib with every
+     * byte still in it (zlib reads plain text and gzip alike) */
+    const int regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    if (regular && pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
         const int64_t size = (int64_t)st.st_size;
         char *b = (char *)malloc((size_t)size + 16);
         if (!b) { close(fd); return PHX_E_NOMEM; }
@@ -91,9 +93,8 @@ static int slurp(const char *path, char **out, int64_t *len) {
         *out = b; *len = n;
         return PHX_OK;
     }
-    close(fd);
-    gzFile g = gzopen(path, "rb");
-    if (!g) return PHX_E_IO;
+    gzFile g = gzdopen(fd, "rb"); /* takes the descriptor over (position 0: nothing has been read from it) */
+    if (!g) { close(fd); return PHX_E_IO; }
     gzbuffer(g, 1 << 20);
     int64_t cap = 1 << 22, n = 0;
     char *b = (char *)malloc((size_t)cap);

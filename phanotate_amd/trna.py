@@ -3,9 +3,9 @@ temporary FASTA, runs `aragorn -t -w` and `tRNAscan-SE -B -q --brief` if they ar
 of [start, stop] pairs (reversed for hits on the complement strand).  libphx takes that list (phx_set_trnas) and adds the
 tRNA nodes and edges on the GPU.  Same commands, same parsing, same warning when neither tool exists."""
 import ast
+import subprocess
 import sys
 import tempfile
-from subprocess import PIPE, Popen
 
 
 def parse_aragorn(text, trnas, seen):
@@ -31,6 +31,28 @@ def parse_trnascan(text, trnas, seen):
             trnas.append([a, b])
 
 
+def _tool_output(cmd):
+    """stdout of a finder.  The child is waited for and its stderr is discarded (the reference reads stdout of a Popen with stderr on
+    an unread pipe: a tool that writes more than a pipe buffer of diagnostics would block forever, and nothing reaps the process)."""
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL).stdout
+
+
+def find_trnas_many(seqs, workers=8):
+    """find_trnas for the contigs of a batch, the finder processes of several contigs side by side (the reference runs them one
+    contig at a time; per contig the calls are what find_trnas makes, in the same order).  -> list (one entry per contig) or None when
+    no tool exists."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    seqs = list(seqs)
+    if not seqs:
+        return []
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(seqs)))) as ex:
+        hits = list(ex.map(lambda s: find_trnas(s, warn=False), seqs))
+    if any(h is None for h in hits):
+        return None
+    return hits
+
+
 def find_trnas(seq, warn=True):
     """-> list of [start, stop] as add_trnas holds it, or None when neither tool could be started (the reference then skips
     the masking with a warning, functions.py:493-495)."""
@@ -43,12 +65,12 @@ def find_trnas(seq, warn=True):
         f.write(seq.lower())
         f.flush()
         try:  # a parse error ends this tool's contribution and keeps what was read so far, as the reference's bare except does
-            out2 = Popen(["aragorn", "-t", "-w", f.name], stdout=PIPE, stdin=PIPE, stderr=PIPE).stdout.read()
+            out2 = _tool_output(["aragorn", "-t", "-w", f.name])
             parse_aragorn(out2.decode(), trnas, seen)
         except Exception:
             pass
         try:
-            out1 = Popen(["tRNAscan-SE", "-B", "-q", "--brief", f.name], stdout=PIPE, stdin=PIPE, stderr=PIPE).stdout.read()
+            out1 = _tool_output(["tRNAscan-SE", "-B", "-q", "--brief", f.name])
             parse_trnascan(out1.decode(), trnas, seen)
         except Exception:
             pass

@@ -1,0 +1,165 @@
+"""BASELINE config 5 at full size on the production code path, on the one GPU a test box has: 8 ranks x 1250 contigs
+(shard.partition of seeds 0..9999), every rank its own libphx contexts, the flat gene arrays gathered to rank 0 as fixed-dtype
+CPU tensors (shard.gather_flat over the group's gloo half) — byte-equal to one process annotating the 10 000 contigs, and a
+sample of them equal to the oracle.  Only the barrier / scalar reductions differ from an 8-GPU launch (gloo instead of RCCL,
+because RCCL refuses two ranks on one device); the RCCL + gloo group itself is brought up once with a single rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _torchrun(nproc, port, script, *args, timeout=1500):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(args)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+def test_config5_eight_ranks_on_one_gpu_equal_one_process_and_the_oracle(tmp_path, oracle):
+    import phanotate_amd as pa
+
+    out = tmp_path / "merged.npz"
+    r = _torchrun(8, 29551, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--smoke-single-device", "--no-extras", "--no-pipeline",
+                  "--dump-merged", str(out))
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["contigs_total"] == 10000 and d["config"]["contigs_rank0"] == 1250
+    assert d["config"]["contigs_with_error_status"] == 0
+    m = np.load(out)
+    st8, offs8, g8 = m["status"], m["offsets"], m["genes"]
+    assert len(st8) == 10000 and len(offs8) == 10001 and d["config"]["genes_called_total"] == len(g8)
+    # the same 10 000 contigs in one process, one batch
+    seqs = [pa.synth_contig(i, 50000) for i in range(10000)]
+    ann = pa.Annotator(device=0)
+    st1, offs1, g1 = ann.annotate_flat(seqs)
+    ann.close()
+    assert st8.tobytes() == st1.tobytes()
+    assert offs8.tobytes() == offs1.tobytes()
+    assert g8.tobytes() == g1.tobytes()
+    assert (st1 == 0).all() and (np.diff(offs1) > 20).all()
+    for i in range(0, 10000, 97):  # ... and the oracle's genes for every 97th contig
+        o = oracle.run(seqs[i])
+        g = g8[offs8[i] : offs8[i + 1]]
+        assert o["status"] == 0
+        assert np.array_equal(g["left"], o["gene_left"]) and np.array_equal(g["right"], o["gene_right"]), i
+        assert np.array_equal(g["strand"], o["gene_strand"].astype(np.int32)) and np.array_equal(g["frame"], o["gene_frame"].astype(np.int32)), i
+        np.testing.assert_allclose(g["score"], o["gene_score"], rtol=1e-9)
+
+
+def test_rccl_plus_gloo_group_comes_up_with_one_rank():
+    """shard.init_group's production branch ("cpu:gloo,cuda:nccl", device bound): barrier and all_reduce on the GPU over RCCL, the
+    gather over gloo — with the single rank a 1-GPU box allows."""
+    r = _torchrun(1, 29552, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "0", "--contigs", "40", "--length", "20000",
+                  "--no-extras", "--no-pipeline", timeout=600)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["contigs_total"] == 40 and d["config"]["contigs_with_error_status"] == 0 and d["value"] > 0
+
+
+def test_cli_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """phanotate.py under torch.distributed.run (cli.py's N > 1 path: partition by length, per-rank batches, gather_flat, rank 0
+    writes in input order): same bytes as the single-process run."""
+    import phanotate_amd as pa
+
+    fa = tmp_path / "in.fasta"
+    with open(fa, "w") as f:
+        for c in ("phiX174", "edge_L200", "synth6k_100", "edge_bridge", "NC_001416.1"):
+            g, name, seq = load_golden(c)
+            f.write(">%s\n%s\n" % (name, seq))
+        for i in range(37):
+            f.write(">s%d\n%s\n" % (i, pa.synth_contig(7000 + i, 3000 + 911 * i).decode()))
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), str(fa)], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr
+    out = tmp_path / "two.tsv"
+    _torchrun(2, 29553, os.path.join(ROOT, "phanotate.py"), "--single-device-ranks", "--device", "0", "-o", str(out), str(fa), timeout=600)
+    assert out.read_text() == one.stdout and one.stdout.count("#id:") == 42
+
+
+# ---- f-4: the other output formats, through the GPU path (README.md:45-54, 60-61, 67-68) ----
+def _cli(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_cli_genbank_fna_faa_on_phix174_match_the_readme():
+    fa = os.path.join(ROOT, "tests", "golden", "phiX174.fasta.gz")
+    gb = _cli("-f", "genbank", fa).split("\n")
+    # README.md:45-54
+    assert gb[:10] == ["LOCUS       phiX174                 5386 bp ",
+                       "FEATURES             Location/Qualifiers",
+                       "     CDS             100..627",
+                       "                     /note=score:-4.827981E+02",
+                       "     CDS             687..1622",
+                       "                     /note=score:-4.857517E+06",
+                       "     CDS             1686..3227",
+                       "                     /note=score:-3.785434E+10",
+                       "     CDS             3224..3484",
+                       "                     /note=score:-3.779878E+02"]
+    assert "ORIGIN" in gb and gb[-2] == "//"
+    g, name, seq = load_golden("phiX174")
+    fna = _cli("-f", "fna", fa).split("\n")
+    assert fna[0] == ">phiX174_CDS_[100..627] [note=score:-4.827981E+02]"  # README.md:60
+    assert fna[1] == seq[99:627].lower() and fna[1].startswith("atgtttcagacttttatttctcgccataattcaaactttttttctgataag")  # README.md:61
+    assert len(fna) == 2 * len(g["gene_left"]) + 1
+    assert _cli("-f", "fasta", fa).split("\n") == fna  # phanotate.py:25-26
+    faa = _cli("-f", "faa", fa).split("\n")
+    assert faa[0] == ">phiX174_CDS_[100..627] [note=score:-4.827981E+02]"  # README.md:67
+    assert faa[1] == "MFQTFISRHNSNFFSDKLVLTSVTPASSAPVLQTPKATSSTLYFDSLTVNAGNGGFLHCIQMDTSVNAANQVVSVGADIAFDADPKFFACLVRFESSSVPTTLPTAYDVYPLNGRHDGGYYTVKDCVTIDVLPRTPGNNVYVGFMVWSNFTATKCRGLVSLNQVIKEIICLQPLK*"  # README.md:68
+    # every record is the gene of the golden path, reverse-strand ones reverse-complemented
+    comp = str.maketrans("acgt", "tgca")
+    for k in range(len(g["gene_left"])):
+        s = seq[int(g["gene_left"][k]) - 1 : int(g["gene_right"][k])].lower()
+        if g["gene_strand"][k] < 0:
+            s = s.translate(comp)[::-1]
+            assert fna[2 * k].startswith(">phiX174_CDS_[complement(%d..%d)]" % (g["gene_left"][k], g["gene_right"][k]))
+        assert fna[2 * k + 1] == s
+        assert len(faa[2 * k + 1]) == len(s) // 3 and faa[2 * k + 1].endswith("*")
+
+
+def test_cli_formats_with_trna_features(tmp_path):
+    """A contig whose path runs through a tRNA (fixture generated through the reference with a fake aragorn): the tRNA shows as a
+    `tRNA` key in genbank (phanotate.py:75 passes left.gene as the feature type), and is left out of the tabular text
+    (locus.py:42) and of fna / faa, which hold CDS records."""
+    from conftest import golden_cases
+
+    case = None
+    for c in golden_cases():
+        if c.startswith("trna_"):
+            g, name, seq = load_golden(c)
+            if not str(g["error"]) and "gene_frame" in g and (np.abs(g["gene_frame"]) == 4).any():
+                case = c
+                break
+    assert case, "no tRNA fixture has a tRNA feature on its path"
+    # a fake aragorn on PATH that prints the text the fixture was generated with (`aragorn -t -w` batch form, tests/golden/make_golden.py)
+    bind = tmp_path / "bin"
+    bind.mkdir()
+    (tmp_path / "hits.txt").write_text(str(g["aragorn_text"]))
+    (bind / "aragorn").write_text("#!/bin/sh\ncat %s\n" % (tmp_path / "hits.txt"))
+    os.chmod(bind / "aragorn", 0o755)
+    fa = tmp_path / "t.fa"
+    fa.write_text(">%s\n%s\n" % (name, seq))
+    env = dict(os.environ, PATH=str(bind) + os.pathsep + os.environ["PATH"])
+
+    def cli(fmt):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), "-f", fmt, str(fa)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+
+    assert cli("tabular") == str(g["tabular"])
+    n_trna = int((np.abs(g["gene_frame"]) == 4).sum())
+    n_cds = len(g["gene_left"]) - n_trna
+    gb = cli("genbank")
+    assert gb.count("\n     tRNA            ") == n_trna and gb.count("\n     CDS             ") == n_cds
+    k = int(np.nonzero(np.abs(g["gene_frame"]) == 4)[0][0])
+    loc = "%d..%d" % (g["gene_left"][k], g["gene_right"][k])
+    assert ("     tRNA            " + (loc if g["gene_strand"][k] > 0 else "complement(%s)" % loc) + "\n") in gb
+    for fmt in ("fna", "faa"):
+        txt = cli(fmt)
+        assert txt.count(">") == n_cds and "tRNA" not in txt and "[" + loc + "]" not in txt

@@ -1051,6 +1051,49 @@ def test_random_trna_hits_against_oracle(pa, oracle):
     ann.close()
 
 
+def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
+    """PHX_CREATE_SOLVER_GLOBAL / _NO_WAVE / _NO_GRAPH / _SIZE_EVERY_RUN (phx_create_ex; they replace round 2's environment switches):
+    the same genes, byte for byte, whichever shortest-path kernel solves the contigs and however the run is enqueued."""
+    seqs = [pa.synth_contig(300 + i, 9000 + 1300 * i) for i in range(12)]
+    base = pa.Annotator()
+    want = base.annotate_flat(seqs)
+    assert all(base.globals(i).sssp_kernel == 2 for i in range(len(seqs)))
+    base.close()
+    for flags, kern in ((("solver_global",), 0), (("solver_no_wave",), 1), (("no_graph", "size_every_run"), 2)):
+        a = pa.Annotator(flags=flags)
+        got = a.annotate_flat(seqs)
+        for _ in range(3):
+            a.run()
+        again = a.download_flat()
+        assert all(a.globals(i).sssp_kernel == kern for i in range(len(seqs))), flags
+        for x, y, z in zip(want, got, again):
+            assert x.tobytes() == y.tobytes() == z.tobytes(), flags
+        a.close()
+    import ctypes as C
+    from phanotate_amd import _lib
+    h = C.c_void_p()
+    assert _lib.lib().phx_create_ex(C.byref(pa.make_params()), 0, None, 1 << 9, C.byref(h)) == -1  # unknown flag
+
+
+def test_trna_hit_outside_the_contig_fails_that_contig_only(pa, oracle):
+    """phx_set_trnas: a hit with an end beyond 1..L (a finder run on a circular topology, a truncated parse) gives that contig the
+    status PHX_S_BADTRNA; the other contigs of the batch run with their own hits (it used to fail the whole batch, and a
+    forward start at L + 1 slipped through one position past the node bitmaps)."""
+    seqs = [pa.synth_contig(900 + i, 7000 + 500 * i) for i in range(5)]
+    L = [len(s) for s in seqs]
+    hits = [[(1200, 1275)], [(L[1] - 40, L[1] + 33)], [(L[2] + 1, L[2] + 2)], [(80, -5)], [(3080, 3000), (5000, 5080)]]
+    ann = pa.Annotator()
+    res = ann.annotate(seqs, trnas=hits)
+    assert [r[0] for r in res] == [0, -4, -4, -4, 0]
+    assert all(len(res[i][1]) == 0 for i in (1, 2, 3))
+    for i in (0, 4):
+        o = oracle.run(seqs[i], trnas=hits[i])
+        check_contig(ann, i, seqs[i], o, res[i][1], res[i][0])
+    res2 = ann.annotate(seqs, trnas=[[], [], [], [], []])  # the statuses do not stick to the context
+    assert [r[0] for r in res2] == [0] * 5
+    ann.close()
+
+
 @pytest.mark.parametrize("ncodons", [2200, 3000, 3800])
 def test_256_bit_contigs_on_the_wavefront_kernel(pa, oracle, ncodons):
     """A 6.6-11 kb stop-free reading frame in an otherwise ordinary 40 kb contig: the path sums need more than 128 bits (a

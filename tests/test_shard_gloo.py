@@ -1,5 +1,5 @@
-"""The N>1 path on CPU: world_size 2 over gloo.  The GPU compute is replaced by a checksum so that the
-sharding / gather-in-input-order plumbing of phanotate_amd.shard is what is under test."""
+"""The N>1 path on CPU: world_size 2 over gloo.  The GPU compute is replaced by a fake so that the
+sharding / gather-in-input-order plumbing of phanotate_amd.shard (init_group, partition, gather_flat, merge_flat) is what is under test."""
 import hashlib
 import os
 import subprocess
@@ -13,23 +13,14 @@ WORKER = textwrap.dedent(
     import hashlib, os, sys
     sys.path.insert(0, %r)
     import torch.distributed as dist
-    from phanotate_amd.shard import run_sharded, partition
+    from phanotate_amd.shard import init_group, partition
     import phanotate_amd as pa
     rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dist, red_dev = init_group(rank, world, device=None)  # no GPU here: the gloo half of the production group
+    assert red_dev == "cpu"
     seqs = [pa.synth_contig(s, 500 + 137 * s) for s in range(23)]
-    calls = []
-    def fake_annotate(batch):
-        calls.append(len(batch))
-        return [(0, hashlib.md5(s).hexdigest()) for s in batch]
-    out = run_sharded(seqs, fake_annotate, rank, world, dist)
     parts = partition([len(s) for s in seqs], world)
-    assert calls == [len(parts[rank])]
-    if rank == 0:
-        assert out == [(0, hashlib.md5(s).hexdigest()) for s in seqs]
-    else:
-        assert out is None
-    # the flat protocol (three arrays per rank instead of one object per contig): bench.py's and the CLI's N > 1 path
+    # the flat protocol (fixed-dtype CPU tensors, point to point: shard.gather_flat): bench.py's and the CLI's N > 1 path
     import numpy as np
     from phanotate_amd.shard import run_sharded_flat
     from phanotate_amd import _lib
@@ -47,9 +38,18 @@ WORKER = textwrap.dedent(
             assert np.diff(offs).tolist() == [len(s) %% 5 for s in seqs]
             for i, s in enumerate(seqs):
                 assert g["left"][offs[i]:offs[i + 1]].tolist() == [len(s) + k for k in range(len(s) %% 5)]
-        print("SHARD_OK", [len(p) for p in parts])
     else:
         assert flat is None and flat2 is None
+    # ragged corner cases of the gather: a rank without contigs, contigs without genes
+    few = seqs[:1]
+    def fake_none(batch):
+        return np.zeros(len(batch), np.int32), np.zeros(len(batch) + 1, np.int64), np.zeros(0, _lib.GENE_DT)
+    e1 = run_sharded_flat(few, fake_flat, rank, world, dist)
+    e2 = run_sharded_flat(seqs, fake_none, rank, world, dist)
+    if rank == 0:
+        assert len(e1[0]) == 1 and np.diff(e1[1]).tolist() == [len(few[0]) %% 5]
+        assert len(e2[0]) == len(seqs) and int(e2[1][-1]) == 0 and len(e2[2]) == 0
+        print("SHARD_OK", [len(p) for p in parts])
     dist.barrier()
     dist.destroy_process_group()
     """
