@@ -495,6 +495,22 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     build_dparams(params, &dp);
     std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
     phx_rbs_table(t6.data(), t5.data(), t4.data(), t3.data());
+    // the device tables hold score SETS (bit s = a rule of score s matches; k_features ORs them over a window and masks every offset
+    // by its class): that needs every score to belong to one offset class, and the packed best-per-class word to turn into bits
+    {
+        const uint32_t cm[4] = {RBS_CLS0, RBS_CLS1, RBS_CLS2, RBS_CLS3};
+        for (const RbsRule &r : kRules)
+            if (r.score < 1 || r.score > 27 || !((cm[r.cls] >> r.score) & 1u)) { c->err = "rbs score classes"; return fail(PHX_E_STATE); }
+    }
+    auto to_set = [](uint32_t packed) {
+        uint32_t m = 0;
+        for (int k = 0; k < 4; k++) { const uint32_t b = (packed >> (8 * k)) & 0xffu; if (b) m |= 1u << b; }
+        return m;
+    };
+    for (uint32_t &x : t6) x = to_set(x);
+    for (uint32_t &x : t5) x = to_set(x);
+    for (uint32_t &x : t4) x = to_set(x);
+    for (uint32_t &x : t3) x = to_set(x);
     // compact device tables: every motif starts with ag, ga or gg (codes a0 c1 t2 g3; symbol j at bits 2j)
     const uint32_t pair_code[3] = {0u | (3u << 2), 3u | (0u << 2), 3u | (3u << 2)};
     std::vector<uint32_t> c6(768), c5(192), c4(48), c3(12);
@@ -1201,7 +1217,7 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
             cls[p] = v;
         }
     }
-    if (gcc) { // the device keeps the GC-frame classes bit-sliced: 9 forward + 9 reverse class bitmaps per frame
+    if (gcc) { // the device keeps the GC-frame classes bit-sliced: three comparison bitmaps per strand and frame
         const size_t nw = (size_t)m.nw;
         std::vector<uint64_t> bits((size_t)PHX_BITMAP_WORDS_PER_NW * nw);
         if (nw) HIPCHK(c, hipMemcpy(bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, bits.size() * 8, hipMemcpyDeviceToHost));
@@ -1210,9 +1226,10 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
             uint8_t g = 0;
             if (p + 3 <= L) {
                 auto bit = [&](int id) { return (int)((bits[((size_t)id * 3 + f) * nw + (k >> 6)] >> (k & 63)) & 1ull); };
-                const int fmx = bit(4) ? 0 : (bit(5) ? 1 : 2), fmn = bit(6) ? 0 : (bit(7) ? 1 : 2);
-                const int rmx = bit(8) ? 0 : (bit(9) ? 1 : 2), rmn = bit(10) ? 0 : (bit(11) ? 1 : 2);
-                g = (uint8_t)((fmx * 3 + fmn) | ((rmx * 3 + rmn) << 4));
+                // planes a > b, b > c, a > c (and c > b, b > a, c > a for the reversed triple): gc_frame_plot.py:7-28
+                auto cls = [&](int base) { const int A = bit(base), B = bit(base + 1), C = bit(base + 2); return ((A && C) ? 0 : ((!A && B) ? 1 : 2)) * 3 + ((!A && !C) ? 0 : ((A && !B) ? 1 : 2)); };
+                const int fc = cls(PHX_PLANE_GCF), rc = cls(PHX_PLANE_GCR);
+                g = (uint8_t)(fc | (rc << 4));
             }
             gcc[p] = g;
         }

@@ -19,9 +19,20 @@
 #define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
 #define PHX_FEAT_THREADS 256
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
-#define PHX_N_CODON_BITMAPS 14 // fwd start, rev start, fwd stop, rev stop; GC frame: max_idx==1, ==2, min_idx==1, ==2 for the forward and for the reversed triple; 'atg' on the forward / reverse strand
+#define PHX_N_CODON_BITMAPS 12 // 0-3 fwd start, rev start, fwd stop, rev stop; 4-9 GC frame plot: the comparisons a > b, b > c, a > c of a codon's three window counts and c > b, b > a, c > a for the reversed triple (max_idx / min_idx follow, see gc_planes); 10-11 'atg' on the forward / reverse strand
+#define PHX_PLANE_GCF 4  // first of the three forward comparison planes
+#define PHX_PLANE_GCR 7  // ... of the reversed triple
+#define PHX_PLANE_ATG 10 // 'atg' forward, then reverse
 #define PHX_PRE_G 2 // bitmap words per prefix-popcount record (k_bit_prefix; a power of two <= 8: nw is a multiple of 8)
 #define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
+
+// score_rbs (functions.py:48-138): every score 1..27 belongs to exactly one offset class, so a set of scores is a bit set and the
+// hits of the four classes share one word (k_features; checked against the rule list in phx_create_ex)
+#define RBS_CLS0 ((1u << 1) | (1u << 5) | (1u << 8) | (1u << 11) | (1u << 18) | (1u << 21) | (1u << 23) | (1u << 26))                  // offsets 3-4
+#define RBS_CLS1 ((1u << 9) | (1u << 13) | (1u << 14) | (1u << 15) | (1u << 16) | (1u << 19) | (1u << 22) | (1u << 24) | (1u << 27))   // offsets 5-10
+#define RBS_CLS2 ((1u << 4) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 17) | (1u << 20) | (1u << 25))                               // offsets 11-12
+#define RBS_CLS3 ((1u << 2) | (1u << 3) | (1u << 10))                                                                                   // offsets 13-15
+static_assert((RBS_CLS0 | RBS_CLS1 | RBS_CLS2 | RBS_CLS3) == 0x0ffffffeu && (RBS_CLS0 & RBS_CLS1) == 0 && ((RBS_CLS0 | RBS_CLS1) & RBS_CLS2) == 0 && ((RBS_CLS0 | RBS_CLS1 | RBS_CLS2) & RBS_CLS3) == 0, "every score in one class");
 
 // codon classes, in the elif order of functions.py:198-215
 #define CLS_NONE 0
@@ -213,7 +224,7 @@ struct DBatch {
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
     uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); written whole by k_node_order
-    uint64_t *bits;     // per contig: [22 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
+    uint64_t *bits;     // per contig: [12 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
     int32_t *iprev;     // per (strand, frame, word): the last item in front of it whose word holds a stop codon, -1: none (k_orf<false> -> k_orf<true>)
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
     const DTNode *tnode; // tRNA nodes / edges of the batch (null: none)

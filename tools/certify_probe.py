@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Prototype of the Decimal-vs-fp64 certificate, run on the GPU box:   python tools/certify_probe.py [n] [seed]
+
+libphx solves on W = trunc(fp64(w) * 1000), the reference on W* = trunc(Decimal(w) * 1000).  With a per-edge bound
+|W* - W| <= eps_e, the device's path P is the reference's path whenever a dual certificate holds (LP duality on the scenario
+"P's edges as heavy, every other edge as light as the bounds allow"):
+  tree = the device's shortest-path tree (P = its path to the target), sigma[v] = signed sum of eps along the tree path to v
+  (+ on P, - off P), kappa[v] = last node on that path whose tree edge has eps > 0.  For every non-tree edge e = (u -> v) of a
+  reached u:   r(e) + sigma[u] - sigma[v] - eps_e > 0          (r = d[u] + W_e - d[v], exact)
+  or  r(e) == 0 and eps_e == 0 and kappa[u] == kappa[v]        (a tie that is exact in the reference's integers too).
+The probe checks (1) that eps_e really bounds |W* - W| on every edge (W* replayed by phanotate_amd/dump.py), (2) how many
+contigs the certificate covers, (3) that for the covered ones the Decimal-derived in-order solve gives the same path."""
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+
+import phanotate_amd as pa
+from decimal_check import solve
+from fuzz_gpu import make
+from phanotate_amd.dump import decimal_weights
+
+
+def eps_of(w):
+    """Bound on |trunc(Decimal w * 1000) - trunc(fp64 w * 1000)| from the fp64 weight alone."""
+    if w == -20.0:
+        return 0  # the tRNA edge: a constant in the reference too (functions.py:509)
+    p = w * 1000.0
+    a = abs(p)
+    lg = abs(math.frexp(a)[1]) if a > 0 else 0
+    err = a * (lg + 8) * 2.0 ** -46
+    f = a - math.floor(a) if a < 2.0 ** 52 else 0.0
+    if a < 2.0 ** 52 and min(f, 1.0 - f) > err:
+        return 0
+    return int(math.ceil(err)) + 1
+
+
+def certify(nd, ed, dist, path):
+    V = len(nd)
+    src, dst = ed["src"].tolist(), ed["dst"].tolist()
+    W = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
+    eps = [eps_of(float(x)) for x in ed["w"]]
+    on_path_edge = {}
+    for a, b in zip(path[:-1], path[1:]):
+        on_path_edge[b] = a
+    # tree edge of every reached node: the path's edge on P, else the lowest-index tight in-edge
+    tree = [-1] * V
+    for k in range(len(src)):
+        u, v = src[k], dst[k]
+        if dist[u] is None or dist[v] is None or dist[u] + W[k] != dist[v]:
+            continue
+        if v in on_path_edge:
+            if on_path_edge[v] == u and (tree[v] < 0 or src[tree[v]] != u):
+                tree[v] = k
+        elif tree[v] < 0:
+            tree[v] = k
+    s = V - 2
+    onP = set(path)
+    sigma, kappa = [None] * V, [None] * V
+    sigma[s], kappa[s] = 0, -1
+    order = sorted((v for v in range(V) if dist[v] is not None and v != s), key=lambda v: 0)
+    pending = order
+    while pending:  # parents before children
+        nxt = []
+        for v in pending:
+            k = tree[v]
+            if k < 0:
+                return "no tree edge", 0
+            u = src[k]
+            if sigma[u] is None:
+                nxt.append(v)
+                continue
+            sign = 1 if (v in onP and on_path_edge.get(v) == u) else -1
+            sigma[v] = sigma[u] + sign * eps[k]
+            kappa[v] = v if eps[k] > 0 else kappa[u]
+        if len(nxt) == len(pending):
+            return "tree cycle", 0
+        pending = nxt
+    tset = set(k for k in tree if k >= 0)
+    worst = None
+    for k in range(len(src)):
+        if k in tset:
+            continue
+        u, v = src[k], dst[k]
+        if dist[u] is None:
+            continue
+        r = dist[u] + W[k] - dist[v]
+        if r < 0:
+            return "negative reduced cost", 0
+        rp = r + sigma[u] - sigma[v] - eps[k]
+        if rp > 0:
+            continue
+        if r == 0 and eps[k] == 0 and kappa[u] == kappa[v]:
+            continue
+        worst = (r, rp, k)
+        return "edge %d: r=%d r'=%d eps=%d" % (k, r, rp, eps[k]), 0
+    return "", 1
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.RandomState(seed)
+    seqs = []
+    while len(seqs) < n:
+        s = make(rng)
+        if len(s) <= 12000 and not set(s.lower()) - set("acgt"):
+            seqs.append(s)
+    seqs += [pa.synth_contig(2000 + k, 50000).decode() for k in range(max(2, n // 10))]
+    ann = pa.Annotator()
+    t0 = time.time()
+    n_ok = n_cert = n_same = n_diff = bad_eps = n_edges = n_inexact = ties_cert = 0
+    reasons = []
+    for b0 in range(0, len(seqs), 50):
+        part = seqs[b0 : b0 + 50]
+        res = ann.annotate(part)
+        for i, (status, genes) in enumerate(res):
+            gl = ann.globals(i)
+            if status < 0 or gl.n_node <= 2:
+                continue
+            n_ok += 1
+            nd, ed, wdec = decimal_weights(ann, i, part[i])
+            Wref = [int(w * 1000) for w in wdec]
+            Wdev = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
+            for k in range(len(ed)):
+                e = eps_of(float(ed["w"][k]))
+                n_edges += 1
+                n_inexact += e > 0
+                if abs(Wref[k] - Wdev[k]) > e:
+                    bad_eps += 1
+                    if bad_eps <= 5:
+                        print("EPS TOO SMALL contig %d edge %d: w=%r dev %d ref %d eps %d" % (b0 + i, k, float(ed["w"][k]), Wdev[k], Wref[k], e))
+            dist = ann.dist(i)
+            path = [int(x) for x in ann.path(i)[0]]
+            why, ok = certify(nd, ed, dist, path)
+            p_dec = solve(nd, ed, wdec)
+            same = p_dec == path
+            n_cert += ok
+            ties_cert += ok and gl.tie != 0
+            if ok:
+                n_same += same
+                n_diff += not same
+                if not same:
+                    print("CERTIFIED BUT DIFFERENT contig %d" % (b0 + i))
+            else:
+                reasons.append((b0 + i, len(part[i]), int(gl.tie), why, same))
+    print("certify probe seed %d: %d contigs, %d certified (%d of them with ties), of those %d same / %d different Decimal path; eps violated on %d of %d edges (%d inexact); %.0f s"
+          % (seed, n_ok, n_cert, ties_cert, n_same, n_diff, bad_eps, n_edges, n_inexact, time.time() - t0))
+    for r in reasons[:40]:
+        print("  uncertified contig %d (L %d, tie flag %d): %s; Decimal path %s" % (r[0], r[1], r[2], r[3], "same" if r[4] else "DIFFERENT"))
+
+
+if __name__ == "__main__":
+    main()
