@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define PHX_VERSION 210 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait */
+#define PHX_VERSION 300 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait;
+                         * 0.3.0: phx_certified, phx_globals.certified, PHX_S_BADTRNA, more PHX_CREATE_* flags */
 #define PHX_MAX_CODONS 16
 
 /* library-level errors */
@@ -129,6 +130,7 @@ typedef struct phx_globals {
                                * 2 spill list full, 3 no convergence, 4 too many step-backs */
     int32_t tie; /* equal-length alternatives to the shortest path (the reference's relaxation order decides, see phx_inorder.inc):
                   * 0 none, 1 they exist and the solver's path already was the reference's, 2 the path was replaced by the reference's */
+    int32_t certified; /* phx_certified's verdict for this contig (1 / 0 / -1) */
     /* the integer counters behind the fp64 globals above (what a Decimal restatement of the reference starts from, see
      * phanotate_amd/dump.py): RBS bin counts without the pseudo-count (functions.py:155-156,168-169,211), GC-frame training
      * counts (functions.py:261-279, index 1..3), g+c over the contig after the counting remap of functions.py:159-163 */
@@ -162,6 +164,10 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_SIZE_EVERY_RUN 4u
 #define PHX_CREATE_SOLVER_GLOBAL 8u
 #define PHX_CREATE_SOLVER_NO_WAVE 16u
+/* The certificate of phx_certified is computed by default; NO_CERTIFY leaves the kernel out (phx_certified then reports -1).
+ * CERT_TIGHT multiplies its error bounds by 2^24, so that ordinary inputs come out uncertified (tests of the host re-solve). */
+#define PHX_CREATE_NO_CERTIFY 32u
+#define PHX_CREATE_CERT_TIGHT 64u
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 
@@ -197,6 +203,15 @@ int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] 
  * genes == NULL only offsets, status and total are filled (size query); cap = number of phx_gene records genes can take. */
 int phx_download_flat(phx_ctx *ctx, phx_gene *genes, int64_t cap, int64_t *offsets /* [n+1] */, int32_t *status /* [n] */, int64_t *total);
 
+/* Is every gene list proven to be what the REFERENCE'S integers give?  libphx solves on trunc(fp64(w) * 1000), the reference on
+ * trunc(Decimal(w) * 1000) with 28 digits (edges.py:17-23); for |w| beyond ~1e13 the two differ in their low digits.  After the
+ * solve the device proves, per contig and in exact integer arithmetic, that no such difference can change the path (an optimality
+ * certificate for every weight vector inside the error bounds, csrc/phx_certify.inc).  cert[i] = 1: proven (also for contigs with
+ * an error status or without a path); 0: not proven — the genes are the exact solution for the fp64-derived integers and in all
+ * likelihood the reference's too, but a caller that needs the guarantee solves contig i again on the Decimal-derived integers
+ * (phanotate_amd/api.py does: Annotator.resolve_uncertified); -1: the context was created with PHX_CREATE_NO_CERTIFY. */
+int phx_certified(phx_ctx *ctx, int8_t *cert /* [n] */);
+
 /* ---- stage taps on the batch last processed by phx_run (parity tests) ---- */
 int phx_tap_globals(phx_ctx *ctx, int32_t contig, phx_globals *out);
 /* per 0-based position, each array L bytes (any may be NULL):
@@ -227,8 +242,8 @@ int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int3
 int phx_set_profiling(phx_ctx *ctx, int on);
 /* The same for a subset of the stages (bit k = stage k; 0 switches profiling off): two events per run instead of two per stage. */
 int phx_set_profiling_stages(phx_ctx *ctx, uint32_t stage_mask);
-/* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k).  (Stage "edge_weights" keeps its
-   index but stays at zero: the overlap weights are evaluated inside the edge fill.) */
+/* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k).  (Stage 10 was "edge_weights" and keeps its
+   index and now times k_certify: the overlap weights are evaluated inside the edge fill.) */
 int phx_get_stage_ms(phx_ctx *ctx, float *ms /* [PHX_N_STAGES] */, int32_t *launches /* [PHX_N_STAGES] */, int reset);
 const char *phx_stage_name(int k);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */

@@ -36,7 +36,7 @@ class Globals(C.Structure):
         ("pos_max", C.c_double * 4), ("pos_min", C.c_double * 4),
         ("n_orf", C.c_int32), ("n_group", C.c_int32), ("n_node", C.c_int32), ("n_edge", C.c_int32), ("n_bridge", C.c_int32),
         ("n_limbs", C.c_int32), ("sssp_sweeps", C.c_int32), ("sssp_iters", C.c_int32), ("status", C.c_int32),
-        ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32), ("tie", C.c_int32),
+        ("sssp_kernel", C.c_int32), ("sssp_handed_back", C.c_int32), ("tie", C.c_int32), ("certified", C.c_int32),
         ("rbs_background_count", C.c_uint32 * 28), ("rbs_training_count", C.c_uint32 * 28), ("gc_max_count", C.c_uint32 * 4), ("gc_min_count", C.c_uint32 * 4),
         ("gc_count", C.c_int64),
     ]
@@ -114,6 +114,7 @@ def lib():
         "phx_wait": (C.c_int, [vp]),
         "phx_download": (C.c_int, [vp, P(Result)]),
         "phx_download_flat": (C.c_int, [vp, vp, i64, vp, vp, P(i64)]),
+        "phx_certified": (C.c_int, [vp, vp]),
         "phx_tap_globals": (C.c_int, [vp, i32, P(Globals)]),
         "phx_tap_positions": (C.c_int, [vp, i32, vp, vp, vp, vp]),
         "phx_tap_orfs": (C.c_int, [vp, i32, vp]),
@@ -147,7 +148,7 @@ def lib():
 
 
 EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_create", "phx_create_ex", "phx_destroy",
-           "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_run_async", "phx_wait", "phx_download", "phx_download_flat", "phx_tap_globals",
+           "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_run_async", "phx_wait", "phx_download", "phx_download_flat", "phx_certified", "phx_tap_globals",
            "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
            "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table", "phx_fasta_read", "phx_fasta_count",
            "phx_fasta_record", "phx_fasta_arrays", "phx_fasta_free", "phx_format_tabular", "phx_free_text"]

@@ -21,8 +21,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_EDGE_WEIGHTS, ST_COPY, ST_INORDER };
-const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "edge_weights", "copies", "inorder"};
+enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_CERTIFY, ST_COPY, ST_INORDER };
+const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "certify", "copies", "inorder"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -90,6 +90,9 @@ struct phx_ctx {
     DevBuf b_tnode, b_tedge, b_tnid, b_tbits; // tRNA masking (phx_set_trnas)
     std::vector<DTNode> h_tnode;               // host copy for the node tap
     bool has_trna = false;
+    DevBuf b_cint, b_csig; // scratch of k_certify (per node)
+    bool certify = true;   // run k_certify after every solve (PHX_CREATE_NO_CERTIFY switches it off)
+    double cert_scale = 1.0;
     DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
     int64_t tie_seen = 0; // largest DTotals.tie_need a run reported
     DevBuf b_ekey;        // phx_solve: rank of every edge in the caller's order
@@ -278,6 +281,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     v = std::min(v, cap_of(c->b_ehit, 8, 8));
     v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
     v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
+    if (c->certify) { v = std::min(v, cap_of(c->b_cint, 20, 8)); v = std::min(v, cap_of(c->b_csig, 16 * (size_t)limbs, 8)); }
     k->node = v;
     k->cb = cap_of(c->b_cbits, 8, 8);
     k->win = std::min(cap_of(c->b_win, sizeof(DWin), 8), cap_of(c->b_wrole, sizeof(uint2) * WIN_ROLES, 8));
@@ -318,6 +322,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
+    b->cint = (int32_t *)c->b_cint.p; b->csig = (uint64_t *)c->b_csig.p; b->cert_scale = c->cert_scale;
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
     b->gpack = gene_pack(c) ? 1 : 0;
@@ -457,7 +462,7 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -476,6 +481,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->no_wave = (flags & PHX_CREATE_SOLVER_NO_WAVE) != 0;
     c->graphs_enabled = (flags & PHX_CREATE_NO_GRAPH) == 0;
     c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
+    c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
+    c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 16777216.0 : 1.0;
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_simd = 4 * cus; }
@@ -539,7 +546,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
+    DevBuf *all[] = {&c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -766,6 +773,10 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_npos, NV * 4))) return rc;
         if ((rc = ensure(c, c->b_ehit, NV * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)std::max(c->n_limbs, 2)))) return rc;
+        if (c->certify) {
+            if ((rc = ensure(c, c->b_cint, NV * 20))) return rc;
+            if ((rc = ensure(c, c->b_csig, NV * 16 * (size_t)std::max(c->n_limbs, 2)))) return rc;
+        }
         const size_t NW = NV / 16 + 8 * (size_t)n + 16; // window records of k_sssp_wave, see k_layout1
         if ((rc = ensure(c, c->b_win, NW * sizeof(DWin)))) return rc;
         if ((rc = ensure(c, c->b_wrole, NW * sizeof(uint2) * WIN_ROLES))) return rc;
@@ -792,6 +803,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_esrc, (size_t)(ht->edge + 1) * 4))) return rc;
         if ((rc = ensure(c, c->b_ew, (size_t)(ht->edge + 1) * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, ((size_t)ht->node + 8) * 8 * (size_t)c->n_limbs))) return rc;
+        if (c->certify && (rc = ensure(c, c->b_csig, ((size_t)ht->node + 8) * 16 * (size_t)c->n_limbs))) return rc;
         HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s));
         mask = ht->class_mask;
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
@@ -857,6 +869,12 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         phxk_inorder(&b, nlm, s);
         if (b.gpack) phxk_gene_pack(&b, s);
     } // equal-length alternatives: the parents of the reference's relaxation order
+    if (c->certify) { // is the path the one the reference's Decimal-derived integers give?  (phx_certify.inc)
+        StageTimer t(c, ST_CERTIFY);
+        int nlm = 0;
+        for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
+        phxk_certify(&b, nlm, s);
+    }
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
@@ -1127,6 +1145,14 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     return PHX_OK;
 }
 
+int phx_certified(phx_ctx *c, int8_t *cert) {
+    if (!c || (!cert && c->n > 0)) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
+    if (!c->ran) return PHX_E_STATE;
+    for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; cert[i] = (int8_t)(!c->certify ? -1 : (m.status < 0 ? 1 : m.cert)); }
+    return PHX_OK;
+}
+
 int phx_annotate(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len, phx_result *out) {
     int rc = phx_upload(c, n, seq, len);
     if (rc) return rc;
@@ -1182,6 +1208,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->sssp_kernel = m.sssp_mode;
     out->sssp_handed_back = m.sssp_why > 0 ? m.sssp_why : 0;
     out->tie = m.tie;
+    out->certified = c->certify ? m.cert : -1;
     for (int i = 0; i < 28; i++) { out->rbs_background_count[i] = m.bg[i]; out->rbs_training_count[i] = m.tr[i]; }
     for (int i = 0; i < 4; i++) { out->gc_max_count[i] = i ? m.pmax[i] : 0u; out->gc_min_count[i] = i ? m.pmin[i] : 0u; }
     out->gc_count = m.gc;

@@ -149,13 +149,14 @@ struct DMeta { // one per contig
     int64_t tn_off, te_off;
     int32_t tie;       // k_inorder: 0 the shortest path is unique, 1 equal-length alternatives exist and the solver's path is the in-order one,
                        // 2 the path was replaced by the in-order one, -1 not resolved (cannot happen)
-    int32_t pad0;
+    int32_t cert;      // k_certify: 1 the path is proven to be the one the reference's Decimal-derived integers give, 0 not proven (phx_certify.inc)
 };
 
 // What the host needs of a contig after every run (the full DMeta record, 0.5 KB, comes over only when a tap asks for it)
 struct DRes {
     int32_t status, n_genes;
     int64_t gene_off;
+    int32_t cert, tie; // DMeta.cert, DMeta.tie
 };
 
 struct DTile {
@@ -258,6 +259,9 @@ struct DBatch {
     const uint32_t *ekey; // optional rank of every edge in the caller's edge order (phx_solve); else the reference's node insertion order is used
     uint8_t *tie;        // scratch of k_inorder (bump-allocated through DTotals.tie_need)
     int64_t tie_cap;
+    int32_t *cint;       // scratch of k_certify: 5 words per node (tree edge, two (link, kappa) pairs),
+    uint64_t *csig;      //   2 x dist_stride limbs per node (sigma, double-buffered)
+    double cert_scale;   // factor on k_certify's error bounds (1; PHX_CREATE_CERT_TIGHT: 2^24, so that the tests see uncertified contigs)
     int32_t defer_overlap; // 1: k_edges<true> queues the overlap edges of a workgroup and evaluates their weights after the neighbour scan (needs node ids < 2^21)
     // output
     int32_t *path;
@@ -289,6 +293,7 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
+void phxk_certify(const DBatch *b, int nl_mask, void *stream); // after k_inorder: DMeta.cert
 void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus

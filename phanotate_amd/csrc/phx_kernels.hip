@@ -18,6 +18,7 @@
 //                  k_sssp_lds<NL> (workgroup / contig),     phx_sssp.inc       integers; path -> genes phanotate.py:65-76,
 //                  k_sssp<NL> + k_path<NL> (global memory)                     locus.py:29-37
 //                  k_inorder (ties between equal-length paths)  phx_inorder.inc    relaxation order of the reference's solver
+//                  k_certify (fp64 vs Decimal weights)      phx_certify.inc    edges.py:17-23: the integers the reference solves on
 //
 // No MFMA anywhere: the path has no dense contraction.  All integer outputs are
 // bit-exact with the reference; fp64 is used where the reference uses Decimal (edge weights only).
@@ -120,6 +121,7 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 #include "phx_layout.inc"
 #include "phx_sssp_wave.inc"
 #include "phx_inorder.inc"
+#include "phx_certify.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -180,6 +182,15 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
         if (nl_mask & 4) hipLaunchKernelGGL((k_inorder<8, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
         if (nl_mask & 8) hipLaunchKernelGGL((k_inorder<17, IO_T_FULL>), g, dim3(IO_T_FULL), 0, s, *b);
     }
+}
+
+void phxk_certify(const DBatch *b, int nl_mask, void *stream) {
+    dim3 g(b->n_contig);
+    hipStream_t s = (hipStream_t)stream;
+    if (nl_mask & 1) hipLaunchKernelGGL(k_certify<2>, g, dim3(CERT_T), 0, s, *b);
+    if (nl_mask & 2) hipLaunchKernelGGL(k_certify<4>, g, dim3(CERT_T), 0, s, *b);
+    if (nl_mask & 4) hipLaunchKernelGGL(k_certify<8>, g, dim3(CERT_T), 0, s, *b);
+    if (nl_mask & 8) hipLaunchKernelGGL(k_certify<17>, g, dim3(CERT_T), 0, s, *b);
 }
 
 void phxk_gene_pack(const DBatch *b, void *stream) {

@@ -1051,6 +1051,87 @@ def test_random_trna_hits_against_oracle(pa, oracle):
     ann.close()
 
 
+def _fuzz_contigs(n, seed, max_len=14000):
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        s = fuzz_gpu.make(rng).lower()
+        if 400 <= len(s) <= max_len and set(s) <= set("acgt"):
+            out.append(s)
+    return out
+
+
+def test_certificate_kernel_equals_its_python_statement(pa):
+    """k_certify (phx_certify.inc) against the prototype it was written from (tools/certify_probe.py: python ints, the same tree,
+    eps, sigma / kappa and per-edge test), contig by contig: with the product's error bounds — where everything certifies — and
+    with the bounds inflated by 2^24 (PHX_CREATE_CERT_TIGHT), where contigs with large ORF weights fail.  Every solver kernel."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import certify_probe
+
+    seqs = _fuzz_contigs(90, 77) + [pa.synth_contig(4000 + k, 30000).decode() for k in range(6)]
+    n_fail = {1.0: 0, 16777216.0: 0}
+    for flags, scale in (((), 1.0), (("cert_tight",), 16777216.0), (("cert_tight", "solver_no_wave"), 16777216.0), (("cert_tight", "solver_global"), 16777216.0)):
+        ann = pa.Annotator(flags=flags)
+        for b0 in range(0, len(seqs), 48):
+            part = seqs[b0 : b0 + 48]
+            ann.upload(part)
+            ann.run()
+            cert = ann.certified()
+            for i in range(len(part)):
+                gl = ann.globals(i)
+                if gl.status < 0 or gl.n_node <= 2:
+                    assert cert[i] == 1
+                    continue
+                path = [int(x) for x in ann.path(i)[0]]
+                if len(path) < 2:
+                    assert cert[i] == 1
+                    continue
+                why, ok = certify_probe.certify(ann.nodes(i), ann.edges(i), ann.dist(i), path, scale)
+                assert int(cert[i]) == ok == gl.certified, (flags, b0 + i, why, int(cert[i]))
+                n_fail[scale] += 1 - ok
+        ann.close()
+    assert n_fail[1.0] == 0 and n_fail[16777216.0] >= 30, n_fail
+    a = pa.Annotator(flags=("no_certify",))
+    a.annotate(seqs[:3])
+    assert (a.certified() == -1).all()
+    a.close()
+
+
+def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, oracle):
+    """The host leg of the guarantee: a contig the device does not certify is solved again on the reference's Decimal-derived
+    integers (Annotator.resolve_uncertified: dump.decimal_weights + the in-order Bellman-Ford in python ints) and its genes are
+    replaced.  With the bounds inflated (cert_tight) that happens to most contigs of a batch: the result must equal the certified
+    run's, byte for byte in the integers, and the oracle's."""
+    seqs = _fuzz_contigs(40, 91, 9000) + [pa.synth_contig(4100, 20000).decode()]
+    plain = pa.Annotator()
+    want = plain.annotate_flat(seqs)
+    assert plain.resolved == [] and (plain.certified() == 1).all()
+    plain.close()
+    tight = pa.Annotator(flags=("cert_tight",))
+    got = tight.annotate_flat(seqs)
+    assert len(tight.resolved) >= 10
+    assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()
+    for f in ("left", "right", "strand", "frame"):
+        assert np.array_equal(got[2][f], want[2][f]), f
+    np.testing.assert_allclose(got[2]["score"], want[2]["score"], rtol=1e-12)
+    raw = tight.download_flat(exact=False)  # what the device itself reported: the same here
+    assert raw[2].tobytes() == want[2].tobytes()
+    for i in tight.resolved[:12]:
+        o = oracle.run(seqs[i])
+        g = got[2][got[1][i] : got[1][i + 1]]
+        assert np.array_equal(g["left"], o["gene_left"]) and np.array_equal(g["right"], o["gene_right"]) and np.array_equal(g["frame"], o["gene_frame"].astype(np.int32))
+    tight.close()
+
+
 def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
     """PHX_CREATE_SOLVER_GLOBAL / _NO_WAVE / _NO_GRAPH / _SIZE_EVERY_RUN (phx_create_ex; they replace round 2's environment switches):
     the same genes, byte for byte, whichever shortest-path kernel solves the contigs and however the run is enqueued."""

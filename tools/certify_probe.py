@@ -25,25 +25,25 @@ from fuzz_gpu import make
 from phanotate_amd.dump import decimal_weights
 
 
-def eps_of(w):
+def eps_of(w, scale=1.0):
     """Bound on |trunc(Decimal w * 1000) - trunc(fp64 w * 1000)| from the fp64 weight alone."""
     if w == -20.0:
         return 0  # the tRNA edge: a constant in the reference too (functions.py:509)
     p = w * 1000.0
     a = abs(p)
     lg = abs(math.frexp(a)[1]) if a > 0 else 0
-    err = a * (lg + 8) * 2.0 ** -46
+    err = a * float(lg + 8) * (scale * 2.0 ** -46)  # the same operations in the same order as cert_eps (phx_certify.inc)
     f = a - math.floor(a) if a < 2.0 ** 52 else 0.0
     if a < 2.0 ** 52 and min(f, 1.0 - f) > err:
         return 0
     return int(math.ceil(err)) + 1
 
 
-def certify(nd, ed, dist, path):
+def certify(nd, ed, dist, path, scale=1.0):
     V = len(nd)
     src, dst = ed["src"].tolist(), ed["dst"].tolist()
     W = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
-    eps = [eps_of(float(x)) for x in ed["w"]]
+    eps = [eps_of(float(x), scale) for x in ed["w"]]
     on_path_edge = {}
     for a, b in zip(path[:-1], path[1:]):
         on_path_edge[b] = a
