@@ -165,9 +165,10 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_SOLVER_GLOBAL 8u
 #define PHX_CREATE_SOLVER_NO_WAVE 16u
 /* The certificate of phx_certified is computed by default; NO_CERTIFY leaves the kernel out (phx_certified then reports -1).
- * CERT_TIGHT multiplies its error bounds by 2^24, so that ordinary inputs come out uncertified (tests of the host re-solve). */
+ * CERT_TIGHT multiplies its error bounds by 2^36, so that ordinary inputs come out uncertified (tests of the host re-solve). */
 #define PHX_CREATE_NO_CERTIFY 32u
 #define PHX_CREATE_CERT_TIGHT 64u
+#define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 7680 nodes) */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 

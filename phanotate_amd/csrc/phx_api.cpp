@@ -93,6 +93,7 @@ struct phx_ctx {
     DevBuf b_cint, b_csig; // scratch of k_certify (per node)
     bool certify = true;   // run k_certify after every solve (PHX_CREATE_NO_CERTIFY switches it off)
     double cert_scale = 1.0;
+    bool cert_wide = false; // test switch: every contig through k_certify_wide
     DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
     int64_t tie_seen = 0; // largest DTotals.tie_need a run reported
     DevBuf b_ekey;        // phx_solve: rank of every edge in the caller's order
@@ -103,6 +104,7 @@ struct phx_ctx {
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
+    int last_vmax = 0;       // largest node count of a contig in the last run (LDS tables of k_certify)
     int64_t last_lds[4] = {0, 0, 0, 0};
     int64_t max_len = 0;
     // steady-state runs replay a captured HIP graph of the whole enqueue (valid while batch layout, buffers and solver classes stand)
@@ -462,7 +464,7 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -482,7 +484,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->graphs_enabled = (flags & PHX_CREATE_NO_GRAPH) == 0;
     c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
-    c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 16777216.0 : 1.0;
+    c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
+    c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_simd = 4 * cus; }
@@ -873,7 +876,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         StageTimer t(c, ST_CERTIFY);
         int nlm = 0;
         for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
-        phxk_certify(&b, nlm, s);
+        phxk_certify(&b, nlm, c->cert_wide ? -1 : (learn ? ht->vmax : c->last_vmax), s);
     }
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
@@ -978,6 +981,7 @@ int finish_once(phx_ctx *c) {
     if (ht->class_mask != c->last_mask || ht->lds_need[0] != c->last_lds[0] || ht->lds_need[1] != c->last_lds[1] || ht->lds_need[2] != c->last_lds[2] || ht->lds_need[3] != c->last_lds[3])
         c->graph_valid = false; // the next run launches other solver kernels / LDS sizes
     c->last_mask = ht->class_mask;
+    if (ht->vmax != c->last_vmax) { c->graph_valid = false; c->last_vmax = ht->vmax; } // (k_certify's LDS size is part of the captured launch)
     for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k];
     if (!covered) return kRetry;
     c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;

@@ -261,7 +261,7 @@ struct DBatch {
     int64_t tie_cap;
     int32_t *cint;       // scratch of k_certify: 5 words per node (tree edge, two (link, kappa) pairs),
     uint64_t *csig;      //   2 x dist_stride limbs per node (sigma, double-buffered)
-    double cert_scale;   // factor on k_certify's error bounds (1; PHX_CREATE_CERT_TIGHT: 2^24, so that the tests see uncertified contigs)
+    double cert_scale;   // factor on k_certify's error bounds (1; PHX_CREATE_CERT_TIGHT: 2^36, so that the tests see uncertified contigs)
     int32_t defer_overlap; // 1: k_edges<true> queues the overlap edges of a workgroup and evaluates their weights after the neighbour scan (needs node ids < 2^21)
     // output
     int32_t *path;
@@ -293,7 +293,7 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
-void phxk_certify(const DBatch *b, int nl_mask, void *stream); // after k_inorder: DMeta.cert
+void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream); // after k_inorder: DMeta.cert
 void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus

@@ -184,13 +184,19 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
     }
 }
 
-void phxk_certify(const DBatch *b, int nl_mask, void *stream) {
+// vmax: the largest node count the batch is expected to hold (the last run's): sizes the LDS tables of k_certify (8 bytes per node, at
+// most 60 KB); a contig with more nodes than that goes through k_certify_wide, launched right behind (it returns at once otherwise)
+void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream) {
     dim3 g(b->n_contig);
     hipStream_t s = (hipStream_t)stream;
-    if (nl_mask & 1) hipLaunchKernelGGL(k_certify<2>, g, dim3(CERT_T), 0, s, *b);
-    if (nl_mask & 2) hipLaunchKernelGGL(k_certify<4>, g, dim3(CERT_T), 0, s, *b);
-    if (nl_mask & 4) hipLaunchKernelGGL(k_certify<8>, g, dim3(CERT_T), 0, s, *b);
-    if (nl_mask & 8) hipLaunchKernelGGL(k_certify<17>, g, dim3(CERT_T), 0, s, *b);
+    int vcap = ((vmax > 1024 ? vmax : 1024) + 255) & ~255;
+    if (vcap > 7680) vcap = 7680;
+    if (vmax < 0) vcap = 0; // (test switch: everything to k_certify_wide)
+    const size_t lds = (size_t)vcap * 8;
+    if (nl_mask & 1) { hipLaunchKernelGGL(k_certify<2>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<2>, g, dim3(CERT_T), 0, s, *b); }
+    if (nl_mask & 2) { hipLaunchKernelGGL(k_certify<4>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<4>, g, dim3(CERT_T), 0, s, *b); }
+    if (nl_mask & 4) { hipLaunchKernelGGL(k_certify<8>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<8>, g, dim3(CERT_T), 0, s, *b); }
+    if (nl_mask & 8) { hipLaunchKernelGGL(k_certify<17>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<17>, g, dim3(CERT_T), 0, s, *b); }
 }
 
 void phxk_gene_pack(const DBatch *b, void *stream) {
