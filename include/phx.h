@@ -111,7 +111,10 @@ typedef struct phx_node {
 
 typedef struct phx_edge { /* in-edge list order of the device graph: grouped by dst */
     int32_t src, dst;     /* device node ids (position-sorted; source = V-2, target = V-1) */
-    double w;             /* Decimal weight of the reference, in fp64 */
+    double w;             /* Decimal weight of the reference, in fp64 (the solver adds trunc(w * 1000), edges.py:22: the device keeps
+                           * that integer, the tap recomputes w and checks the two against each other) */
+    int32_t inexact;      /* 1: trunc(Decimal(w) * 1000) may differ from trunc(w * 1000) (the eps_e > 0 of phx_certified) */
+    int32_t pad;
 } phx_edge;
 
 typedef struct phx_globals {
@@ -168,7 +171,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
  * CERT_TIGHT multiplies its error bounds by 2^36, so that ordinary inputs come out uncertified (tests of the host re-solve). */
 #define PHX_CREATE_NO_CERTIFY 32u
 #define PHX_CREATE_CERT_TIGHT 64u
-#define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 7680 nodes) */
+#define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 

@@ -83,7 +83,9 @@ struct phx_ctx {
     std::vector<DTile> tiles;
     const void *attached = nullptr;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
+    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_owi, b_oflag, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
+    DevBuf b_ewf, b_esrcf;   // fp64 weights and plain sources of the batch last run, recomputed for the edge tap (k_edges<true, true>)
+    bool tapw_valid = false; // ... are those of the run whose results the context holds
     int64_t tot_nbits = 0, tot_bridge = 0;
     int64_t tot_words = 0, tot_items = 0;
     DevBuf b_win, b_wrole;
@@ -274,7 +276,7 @@ static inline int64_t gene_half(const phx_ctx *c) { return (int64_t)(c->b_genes.
 
 void current_caps(const phx_ctx *c, DCaps *k) {
     const int limbs = c->n_limbs > 2 ? c->n_limbs : 2;
-    k->orf = std::min(std::min(cap_of(c->b_orf, sizeof(DOrf), 1), cap_of(c->b_ostat, sizeof(DOrfStat), 1)), std::min(cap_of(c->b_oweight, 8, 1), cap_of(c->b_onode, 4, 1)));
+    k->orf = std::min(std::min(cap_of(c->b_orf, sizeof(DOrf), 1), cap_of(c->b_ostat, sizeof(DOrfStat), 1)), std::min(std::min(cap_of(c->b_oweight, 8, 1), cap_of(c->b_owi, 8, 1)), std::min(cap_of(c->b_onode, 4, 1), cap_of(c->b_oflag, 1, 8))));
     k->grp = std::min(cap_of(c->b_grp, sizeof(DGrp), 1), cap_of(c->b_genes, 2 * sizeof(DGene), 1) - (int64_t)c->h_tnode.size()); // a path k_inorder replaces may take new gene slots; tRNA features are genes too
     int64_t v = cap_of(c->b_node, sizeof(DNode), 8);
     for (const DevBuf *q : {&c->b_parent, &c->b_path, &c->b_olist}) v = std::min(v, cap_of(*q, 4, 8));
@@ -312,7 +314,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->bridge = (DBridge *)c->b_bridge.p;
     if (c->has_trna) { b->tnode = (const DTNode *)c->b_tnode.p; b->tedge = (const DTEdge *)c->b_tedge.p; b->tnid = (int32_t *)c->b_tnid.p; b->tbits = (uint64_t *)c->b_tbits.p; }
     b->orf = (DOrf *)c->b_orf.p; b->grp = (DGrp *)c->b_grp.p;
-    b->ostat = (DOrfStat *)c->b_ostat.p; b->oweight = (double *)c->b_oweight.p; b->onode = (int32_t *)c->b_onode.p;
+    b->ostat = (DOrfStat *)c->b_ostat.p; b->oweight = (double *)c->b_oweight.p; b->owi = (long long *)c->b_owi.p; b->oflag = (uint8_t *)c->b_oflag.p; b->onode = (int32_t *)c->b_onode.p;
     b->node = (DNode *)c->b_node.p; b->parent = (int32_t *)c->b_parent.p;
     b->in_off = (uint32_t *)c->b_inoff.p;
     b->no = (double *)c->b_no.p;
@@ -322,7 +324,8 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
-    b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (double *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
+    b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
+    b->esrcf = nullptr; b->ewf = nullptr;
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->cint = (int32_t *)c->b_cint.p; b->csig = (uint64_t *)c->b_csig.p; b->cert_scale = c->cert_scale;
     b->path = (int32_t *)c->b_path.p;
@@ -549,7 +552,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
+    DevBuf *all[] = {&c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -765,6 +768,8 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_orf, sizeof(DOrf) * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_ostat, sizeof(DOrfStat) * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_oweight, 8 * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_owi, 8 * (size_t)(ht->orf + 1)))) return rc;
+        if ((rc = ensure(c, c->b_oflag, (size_t)(ht->orf + 16)))) return rc;
         if ((rc = ensure(c, c->b_onode, 4 * (size_t)(ht->orf + 1)))) return rc;
         if ((rc = ensure(c, c->b_grp, sizeof(DGrp) * G))) return rc;
         if ((rc = ensure(c, c->b_genes, 2 * sizeof(DGene) * (G + c->h_tnode.size() + 8)))) return rc;
@@ -901,6 +906,7 @@ void drop_graph(phx_ctx *c) {
 // later kernels then do nothing, and the caller runs again with `learn`.
 int launch_once(phx_ctx *c, bool learn) {
     int rc;
+    c->tapw_valid = false;
     hipStream_t s = c->stream;
     if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
     if ((rc = ensure_position_buffers(c))) return rc;
@@ -1360,18 +1366,53 @@ int phx_tap_nodes(phx_ctx *c, int32_t contig, phx_node *out) {
     return PHX_OK;
 }
 
+// fp64 weights and plain source nodes of the whole batch, recomputed once per run for the taps (the run keeps the integers the
+// solver adds, not the doubles they were truncated from)
+static int ensure_tap_weights(phx_ctx *c) {
+    if (c->tapw_valid) return PHX_OK;
+    int rc;
+    const size_t E = (size_t)c->tot_edge;
+    if ((rc = ensure(c, c->b_esrcf, (E + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->b_ewf, (E + 1) * 8))) return rc;
+    DBatch b;
+    fill_batch(c, &b);
+    b.esrcf = (uint32_t *)c->b_esrcf.p; b.ewf = (double *)c->b_ewf.p;
+    b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0;
+    phxk_edges_tap(&b, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tapw_valid = true;
+    return PHX_OK;
+}
+
 int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
     TAP_PRE(c, contig);
     if (m.status < 0 || m.n_edge == 0) return PHX_OK;
     if (!out) return PHX_E_ARG;
+    { const int rt = ensure_tap_weights(c); if (rt) return rt; }
     const size_t V = (size_t)m.n_node, E = (size_t)m.n_edge;
-    std::vector<uint32_t> in_off(V + 1), esrc(E);
+    std::vector<uint32_t> in_off(V + 1), esrc(E), esrci(E);
     std::vector<double> ew(E);
+    std::vector<long long> ewi(E);
     HIPCHK(c, hipMemcpy(in_off.data(), (uint32_t *)c->b_inoff.p + m.node_off + contig, (V + 1) * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(esrc.data(), (uint32_t *)c->b_esrc.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(ew.data(), (double *)c->b_ew.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(esrc.data(), (uint32_t *)c->b_esrcf.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ew.data(), (double *)c->b_ewf.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
+    // the records the solver read: source | inexact << 31, and the integer trunc(w * 1000) in the encoding of ew_encode
+    HIPCHK(c, hipMemcpy(esrci.data(), (uint32_t *)c->b_esrc.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ewi.data(), (long long *)c->b_ew.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
     for (size_t v = 0; v < V; v++)
-        for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) { out[e].src = (int32_t)esrc[e]; out[e].dst = (int32_t)v; out[e].w = ew[e]; }
+        for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) {
+            out[e].src = (int32_t)esrc[e]; out[e].dst = (int32_t)v; out[e].w = ew[e];
+            // the tap's weight and the solver's integer are two results of one computation: any difference is an error of the library
+            const double t = std::trunc(ew[e] * 1000.0);
+            const long long x = ewi[e];
+            const bool wide = (((unsigned long long)x >> 63) ^ ((unsigned long long)x >> 62)) & 1ull;
+            bool same = (esrci[e] & 0x7fffffffu) == esrc[e];
+            if (wide) { long long bits; memcpy(&bits, &t, 8); same = same && ((x | (1ll << 62)) == bits); }
+            else same = same && std::fabs(t) < 4611686018427387904.0 && (long long)t == x;
+            if (!same) { c->err = "edge tap: recomputed weight differs from the solver's integer"; return PHX_E_STATE; }
+            out[e].inexact = (int32_t)(esrci[e] >> 31);
+        }
     return PHX_OK;
 }
 
@@ -1469,7 +1510,7 @@ int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_
     b.n_contig = 1;
     b.meta = (DMeta *)b_meta.p;
     b.tot = (DTotals *)c->b_tot.p;
-    b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (double *)c->b_ew.p;
+    b.in_off = (uint32_t *)c->b_inoff.p; b.esrc = (uint32_t *)c->b_esrc.p; b.ew = (long long *)c->b_ew.p;
     b.ewl = (const uint64_t *)c->b_ewl.p;
     b.ekey = (const uint32_t *)c->b_ekey.p;
     b.dist = (uint64_t *)c->b_dist.p; b.parent = (int32_t *)c->b_parent.p;

@@ -8,7 +8,8 @@
 //   per group (index = meta.grp_off + g, device order = (strand, frame, codon); DGrp.evkey = reference insertion order):  DGrp (32 B)
 //   per node  (index = meta.node_off + v, v sorted by position; source = V-2, target = V-1):
 //       DNode {pos i32, info i32, link u32, other i32}, no f64, in_off u32 (+1), dist NL x u64, parent i32
-//   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32, ew f64
+//   per edge  (index = meta.edge_off + e, grouped by destination node):  esrc u32 (source node | inexact << 31), ew i64 (the integer
+//       weight trunc(w * 1000), encoded: see ew_encode in phx_kernels.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,6 +42,9 @@ static_assert((RBS_CLS0 | RBS_CLS1 | RBS_CLS2 | RBS_CLS3) == 0x0ffffffeu && (RBS
 #define CLS_FT 3 // codon in stop_codons
 #define CLS_RT 4 // rev_comp(codon) in stop_codons
 // cls byte (DParams.cls_tab, the cls tap; no per-position array on the device): bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
+
+#define ESRC_NODE(x) ((x) & 0x7fffffffu)
+#define ESRC_INEXACT(x) ((x) >> 31)
 
 // node link word: bits 30-31 kind, bits 0-29 index
 #define LINK_NONE 0u
@@ -237,7 +241,9 @@ struct DBatch {
     // per ORF / group
     DOrf *orf;
     DOrfStat *ostat;    // k_orf_stats -> k_score, k_node_attr
-    double *oweight;    // Orf.weight: k_score -> k_edges, genes
+    double *oweight;    // Orf.weight: k_score -> genes (and the tap variant of k_edges)
+    long long *owi;     // the same as the solver's integer (ew_encode) and
+    uint8_t *oflag;     //   its inexact flag: k_score -> k_edges
     int32_t *onode;     // device node id of the ORF's start node: k_node_build -> k_edges
     DGrp *grp;
     // per node
@@ -253,8 +259,10 @@ struct DBatch {
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
-    uint32_t *esrc;
-    double *ew;
+    uint32_t *esrc;     // source node | inexact << 31 (ESRC_NODE / ESRC_INEXACT)
+    long long *ew;      // integer weight, encoded (ew_encode / ew_decode)
+    uint32_t *esrcf;    // tap variant of k_edges<true> only: plain source nodes and
+    double *ewf;        //   fp64 weights, into scratch of their own
     const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge
     const uint32_t *ekey; // optional rank of every edge in the caller's edge order (phx_solve); else the reference's node insertion order is used
     uint8_t *tie;        // scratch of k_inorder (bump-allocated through DTotals.tie_need)
@@ -287,6 +295,7 @@ void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_edges_tap(const DBatch *b, void *stream); // k_edges<true> once more, writing fp64 weights and plain sources to DBatch.ewf / esrcf (taps)
 void phxk_sssp_order(const DBatch *b, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);

@@ -103,6 +103,45 @@ __device__ __forceinline__ uint64_t row16_sum_u64(uint64_t x, int sub) {
     return x;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Edge records as the kernels keep them (DBatch.esrc / DBatch.ew, 4 + 8 bytes per edge).
+//   ew: the integer the solver works on, W = trunc(w * 1000) (edges.py:22), so that no consumer converts fp64 again: a value with
+//       |W| < 2^62 as it is (bits 63 and 62 equal); a wider one as the bit pattern of the double p = trunc(w * 1000) — whose bit 62 is
+//       always set, |p| >= 2^62 — with bit 62 forced to differ from bit 63, which marks it (ew_decode, phx_sssp.inc, restores it).
+//   esrc: source node in bits 0..30; bit 31 = "inexact": the reference's integer trunc(Decimal(w) * 1000) may differ from W
+//       (k_certify's eps_e > 0, phx_certify.inc) — decided here, where the fp64 weight still exists.
+// The fp64 weights themselves are not kept: the taps recompute them (k_edges<true, true>).
+#define EW_WIDE(x) (((((unsigned long long)(x)) >> 63) ^ (((unsigned long long)(x)) >> 62)) & 1ull)
+__device__ __forceinline__ long long ew_encode(double w) {
+    const double t = trunc(w * 1000.0);
+    if (fabs(t) < 2251799813685248.0) return __double_as_longlong(t + 6755399441055744.0) - 0x4338000000000000ll; // |t| < 2^51: the integer sits in the low mantissa bits of t + 1.5 * 2^52
+    if (fabs(t) < 4611686018427387904.0) return (long long)t;
+    const long long bits = __double_as_longlong(t);
+    return bits < 0 ? (bits & ~(1ll << 62)) : bits;
+}
+// cert_eps(w) == 0 (phx_certify.inc): p = w * 1000 is farther from the next integer than its error bound err = |p| (|exponent| + 8)
+// 2^-46 x scale, so the reference's truncation cannot differ.  c = scale * 2^-46.
+__device__ __forceinline__ bool cert_eps_is_zero_fast(double w, double c) {
+    const double p = w * 1000.0, a = fabs(p);
+    const int ef = (int)(((uint32_t)((unsigned long long)__double_as_longlong(a) >> 52)) & 0x7ffu);
+    int ex = ef - 1022; // frexp's exponent of a normal number (a == 0: no error either way; subnormal weights do not occur)
+    ex = a > 0.0 ? (ex < 0 ? -ex : ex) : 0;
+    const double err = a * (double)(ex + 8) * c;
+    const double f = a - floor(a);
+    const bool far = (f < 1.0 - f ? f : 1.0 - f) > err;
+    return w == -20.0 || (a < 4503599627370496.0 && far);
+}
+#define CERT_C(b) ((b).cert_scale * 1.4210854715202004e-14) // 2^-46
+// one edge weight in registers: what goes to DBatch.ew (the encoded integer; the fp64 bits in the tap variant) and the inexact flag
+struct EWt { unsigned long long bits; uint32_t fl; };
+template <bool TAPW>
+__device__ __forceinline__ EWt make_ew(double w, double c) {
+    EWt r;
+    if (TAPW) { r.bits = (unsigned long long)__double_as_longlong(w); r.fl = 0u; }
+    else { r.bits = (unsigned long long)ew_encode(w); r.fl = cert_eps_is_zero_fast(w, c) ? 0u : 0x80000000u; }
+    return r;
+}
+
 // functions.py:174-178: both strands are counted, so Pa == Pt and Pg == Pc.
 __device__ __forceinline__ double contig_pstop(uint32_t gc, int L) {
     double fa = (double)((uint32_t)L - gc), fg = (double)gc;
@@ -125,6 +164,13 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 
 // ------------------------------------------------------------------------------------------------
 // launchers
+template <int NL>
+static void launch_certify(const DBatch *b, int vcap, hipStream_t s) {
+    const size_t lds = (size_t)vcap * 12 + 16;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k_certify<NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_certify<NL>, dim3(b->n_contig), dim3(CERT_T), lds, s, *b, vcap);
+    hipLaunchKernelGGL(k_certify_wide<NL>, dim3(b->n_contig), dim3(CERT_T), 0, s, *b);
+}
 extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
     if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
@@ -158,6 +204,7 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_tap(const DBatch *b, void *stream) { hipLaunchKernelGGL((k_edges<true, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 // phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
     phxk_sssp(b, nl, 0, 0, stream);
@@ -184,19 +231,17 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
     }
 }
 
-// vmax: the largest node count the batch is expected to hold (the last run's): sizes the LDS tables of k_certify (8 bytes per node, at
-// most 60 KB); a contig with more nodes than that goes through k_certify_wide, launched right behind (it returns at once otherwise)
+// vmax: the largest node count the batch is expected to hold (the last run's): sizes the LDS tables of k_certify (12 bytes per node, at
+// most 144 KB); a contig with more nodes than that goes through k_certify_wide, launched right behind (it returns at once otherwise)
 void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream) {
-    dim3 g(b->n_contig);
     hipStream_t s = (hipStream_t)stream;
     int vcap = ((vmax > 1024 ? vmax : 1024) + 255) & ~255;
-    if (vcap > 7680) vcap = 7680;
+    if (vcap > 12288) vcap = 12288;
     if (vmax < 0) vcap = 0; // (test switch: everything to k_certify_wide)
-    const size_t lds = (size_t)vcap * 8;
-    if (nl_mask & 1) { hipLaunchKernelGGL(k_certify<2>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<2>, g, dim3(CERT_T), 0, s, *b); }
-    if (nl_mask & 2) { hipLaunchKernelGGL(k_certify<4>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<4>, g, dim3(CERT_T), 0, s, *b); }
-    if (nl_mask & 4) { hipLaunchKernelGGL(k_certify<8>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<8>, g, dim3(CERT_T), 0, s, *b); }
-    if (nl_mask & 8) { hipLaunchKernelGGL(k_certify<17>, g, dim3(CERT_T), lds, s, *b, vcap); hipLaunchKernelGGL(k_certify_wide<17>, g, dim3(CERT_T), 0, s, *b); }
+    if (nl_mask & 1) launch_certify<2>(b, vcap, s);
+    if (nl_mask & 2) launch_certify<4>(b, vcap, s);
+    if (nl_mask & 4) launch_certify<8>(b, vcap, s);
+    if (nl_mask & 8) launch_certify<17>(b, vcap, s);
 }
 
 void phxk_gene_pack(const DBatch *b, void *stream) {

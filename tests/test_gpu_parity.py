@@ -1095,7 +1095,9 @@ def test_certificate_kernel_equals_its_python_statement(pa):
                 if len(path) < 2:
                     assert cert[i] == 1
                     continue
-                why, ok = certify_probe.certify(ann.nodes(i), ann.edges(i), ann.dist(i), path, scale)
+                ed = ann.edges(i)
+                assert ed["inexact"].tolist() == [certify_probe.flag_of(float(w), scale) for w in ed["w"]]  # the flag k_edges / k_score set
+                why, ok = certify_probe.certify(ann.nodes(i), ed, ann.dist(i), path, scale, repair="cert_wide" not in flags)
                 assert int(cert[i]) == ok == gl.certified, (flags, b0 + i, why, int(cert[i]))
                 n_fail[scale] += 1 - ok
         ann.close()

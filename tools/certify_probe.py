@@ -25,25 +25,41 @@ from fuzz_gpu import make
 from phanotate_amd.dump import decimal_weights
 
 
-def eps_of(w, scale=1.0):
-    """Bound on |trunc(Decimal w * 1000) - trunc(fp64 w * 1000)| from the fp64 weight alone."""
+def eps_of(w, inexact, scale=1.0):
+    """Bound on |trunc(Decimal w * 1000) - trunc(fp64 w * 1000)|: 0 for an edge the device did not flag (its p = w * 1000 is farther
+    from the next integer than its error bound), else from the integer the solver uses — cert_eps in phx_certify.inc, the same
+    operations in the same order."""
+    if not inexact:
+        return 0
+    t = math.trunc(w * 1000.0)
+    a = float(abs(t)) + 1.0 if abs(t) < 2 ** 62 else abs(float(t))
+    ex = abs(math.frexp(a)[1])
+    err = a * float(ex + 8) * (scale * 2.0 ** -46)
+    return int(math.ceil(err)) + 1
+
+
+def flag_of(w, scale=1.0):
+    """The device's inexact flag, restated (cert_eps_is_zero_fast, phx_kernels.hip)."""
     if w == -20.0:
         return 0  # the tRNA edge: a constant in the reference too (functions.py:509)
     p = w * 1000.0
     a = abs(p)
-    lg = abs(math.frexp(a)[1]) if a > 0 else 0
-    err = a * float(lg + 8) * (scale * 2.0 ** -46)  # the same operations in the same order as cert_eps (phx_certify.inc)
-    f = a - math.floor(a) if a < 2.0 ** 52 else 0.0
-    if a < 2.0 ** 52 and min(f, 1.0 - f) > err:
-        return 0
-    return int(math.ceil(err)) + 1
+    ex = abs(math.frexp(a)[1]) if a > 0 else 0
+    err = a * float(ex + 8) * (scale * 2.0 ** -46)
+    if a < 2.0 ** 52:
+        f = a - math.floor(a)
+        if min(f, 1.0 - f) > err:
+            return 0
+    return 1
 
 
-def certify(nd, ed, dist, path, scale=1.0):
+def certify(nd, ed, dist, path, scale=1.0, repair=True):
+    """The certificate of phx_certify.inc in python ints.  repair=False: the form of k_certify_wide (no corrections)."""
     V = len(nd)
     src, dst = ed["src"].tolist(), ed["dst"].tolist()
     W = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
-    eps = [eps_of(float(x), scale) for x in ed["w"]]
+    flags = ed["inexact"].tolist()
+    eps = [eps_of(float(x), f, scale) for x, f in zip(ed["w"], flags)]
     on_path_edge = {}
     for a, b in zip(path[:-1], path[1:]):
         on_path_edge[b] = a
@@ -62,8 +78,7 @@ def certify(nd, ed, dist, path, scale=1.0):
     onP = set(path)
     sigma, kappa = [None] * V, [None] * V
     sigma[s], kappa[s] = 0, -1
-    order = sorted((v for v in range(V) if dist[v] is not None and v != s), key=lambda v: 0)
-    pending = order
+    pending = [v for v in range(V) if dist[v] is not None and v != s]
     while pending:  # parents before children
         nxt = []
         for v in pending:
@@ -80,25 +95,34 @@ def certify(nd, ed, dist, path, scale=1.0):
         if len(nxt) == len(pending):
             return "tree cycle", 0
         pending = nxt
-    tset = set(k for k in tree if k >= 0)
-    worst = None
-    for k in range(len(src)):
-        if k in tset:
-            continue
-        u, v = src[k], dst[k]
-        if dist[u] is None:
-            continue
-        r = dist[u] + W[k] - dist[v]
-        if r < 0:
-            return "negative reduced cost", 0
-        rp = r + sigma[u] - sigma[v] - eps[k]
-        if rp > 0:
-            continue
-        if r == 0 and eps[k] == 0 and kappa[u] == kappa[v]:
-            continue
-        worst = (r, rp, k)
-        return "edge %d: r=%d r'=%d eps=%d" % (k, r, rp, eps[k]), 0
-    return "", 1
+    delta = [0] * V
+    for rnd in range(26):
+        changed = False
+        for k in range(len(src)):
+            u, v = src[k], dst[k]
+            if dist[u] is None:
+                continue
+            is_tree = tree[v] == k
+            if is_tree and (v in onP or rnd == 0):
+                continue
+            if rnd > 0 and delta[u] == 0:
+                continue
+            r = dist[u] + W[k] - dist[v]
+            if r < 0:
+                return "negative reduced cost", 0
+            r0 = 0 if is_tree else r + sigma[u] - sigma[v] - eps[k]
+            need = delta[u] - r0
+            if v in onP:
+                if not (need < 0 or (r == 0 and eps[k] == 0 and kappa[u] == kappa[v] and delta[u] == 0)):
+                    return "edge %d into the path: r=%d r0=%d eps=%d delta[u]=%d" % (k, r, r0, eps[k], delta[u]), 0
+            elif need > delta[v]:
+                if not repair or need > 60000:
+                    return "edge %d off the path: r=%d r0=%d eps=%d" % (k, r, r0, eps[k]), 0
+                delta[v] = need
+                changed = True
+        if not changed:
+            return "", 1
+    return "corrections do not settle", 0
 
 
 def main():
@@ -127,7 +151,8 @@ def main():
             Wref = [int(w * 1000) for w in wdec]
             Wdev = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
             for k in range(len(ed)):
-                e = eps_of(float(ed["w"][k]))
+                assert int(ed["inexact"][k]) == flag_of(float(ed["w"][k])), "the device's inexact flag differs from its statement"
+                e = eps_of(float(ed["w"][k]), int(ed["inexact"][k]))
                 n_edges += 1
                 n_inexact += e > 0
                 if abs(Wref[k] - Wdev[k]) > e:

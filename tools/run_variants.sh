@@ -8,6 +8,6 @@ for f in tmp_variants/libphx_*.so; do
   timeout 300 python bench.py --steps 5 --warmup 2 --no-extras 2>/tmp/e.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['stage_ms_per_step']
-print('variant $v', d['value'], d['ms_per_step'], 'sssp', s['sssp'], 'features', s['features'], 'efill', s['edges_fill'], 'ecount', s['edges_count'], 'genes', d['config']['genes_called_total'], 'bad', d['config']['contigs_with_error_status'])"
+print('variant $v', d['value'], d['ms_per_step'], 'sssp', s['sssp'], 'features', s['features'], 'efill', s['edges_fill'], 'ecount', s['edges_count'], 'certify', s.get('certify'), 'inorder', s.get('inorder'), 'genes', d['config']['genes_called_total'], 'bad', d['config']['contigs_with_error_status'])"
 done
 cp /tmp/libphx_default.so phanotate_amd/libphx.so
