@@ -167,7 +167,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_SIZE_EVERY_RUN 4u
 #define PHX_CREATE_SOLVER_GLOBAL 8u
 #define PHX_CREATE_SOLVER_NO_WAVE 16u
-/* The certificate of phx_certified is computed by default; NO_CERTIFY leaves the kernel out (phx_certified then reports -1).
+/* NO_CERTIFY: phx_certified reports -1 (and the kernel's scratch, 20 + 32 bytes per node, is not allocated).
  * CERT_TIGHT multiplies its error bounds by 2^36, so that ordinary inputs come out uncertified (tests of the host re-solve). */
 #define PHX_CREATE_NO_CERTIFY 32u
 #define PHX_CREATE_CERT_TIGHT 64u
@@ -213,7 +213,9 @@ int phx_download_flat(phx_ctx *ctx, phx_gene *genes, int64_t cap, int64_t *offse
  * certificate for every weight vector inside the error bounds, csrc/phx_certify.inc).  cert[i] = 1: proven (also for contigs with
  * an error status or without a path); 0: not proven — the genes are the exact solution for the fp64-derived integers and in all
  * likelihood the reference's too, but a caller that needs the guarantee solves contig i again on the Decimal-derived integers
- * (phanotate_amd/api.py does: Annotator.resolve_uncertified); -1: the context was created with PHX_CREATE_NO_CERTIFY. */
+ * (phanotate_amd/api.py does: Annotator.resolve_uncertified); -1: the context was created with PHX_CREATE_NO_CERTIFY.
+ * The proof is computed when it is first asked for after a run (here, or by phx_tap_globals), from the state the run left on the
+ * device — ~0.2 ms for a thousand 50 kb contigs; phx_run itself does not pay for it. */
 int phx_certified(phx_ctx *ctx, int8_t *cert /* [n] */);
 
 /* ---- stage taps on the batch last processed by phx_run (parity tests) ---- */

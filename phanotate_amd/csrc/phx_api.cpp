@@ -93,7 +93,8 @@ struct phx_ctx {
     std::vector<DTNode> h_tnode;               // host copy for the node tap
     bool has_trna = false;
     DevBuf b_cint, b_csig; // scratch of k_certify (per node)
-    bool certify = true;   // run k_certify after every solve (PHX_CREATE_NO_CERTIFY switches it off)
+    bool certify = true;   // phx_certified works (PHX_CREATE_NO_CERTIFY: it reports -1 and the scratch is not allocated)
+    bool cert_done = false; // k_certify has run on the results the context holds
     double cert_scale = 1.0;
     bool cert_wide = false; // test switch: every contig through k_certify_wide
     DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
@@ -877,12 +878,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         phxk_inorder(&b, nlm, s);
         if (b.gpack) phxk_gene_pack(&b, s);
     } // equal-length alternatives: the parents of the reference's relaxation order
-    if (c->certify) { // is the path the one the reference's Decimal-derived integers give?  (phx_certify.inc)
-        StageTimer t(c, ST_CERTIFY);
-        int nlm = 0;
-        for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
-        phxk_certify(&b, nlm, c->cert_wide ? -1 : (learn ? ht->vmax : c->last_vmax), s);
-    }
     HIPCHK(c, hipGetLastError());
     { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
@@ -906,7 +901,7 @@ void drop_graph(phx_ctx *c) {
 // later kernels then do nothing, and the caller runs again with `learn`.
 int launch_once(phx_ctx *c, bool learn) {
     int rc;
-    c->tapw_valid = false;
+    c->tapw_valid = false; c->cert_done = false;
     hipStream_t s = c->stream;
     if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
     if ((rc = ensure_position_buffers(c))) return rc;
@@ -1155,10 +1150,34 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     return PHX_OK;
 }
 
+// The certificate is computed when it is first asked for after a run (k_certify on the state the run left on the device: distances,
+// parent edges, path, edge records), not inside phx_run: a caller that only wants gene lists at full rate does not pay for it.
+static int ensure_cert(phx_ctx *c) {
+    if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    DBatch b;
+    fill_batch(c, &b);
+    int nlm = 0;
+    for (int k = 0; k < 4; k++) nlm |= ((c->last_mask >> (4 * k)) & 7) ? 1 << k : 0;
+    {
+        StageTimer t(c, ST_CERTIFY);
+        phxk_certify(&b, nlm, c->cert_wide ? -1 : c->last_vmax, c->stream);
+        phxk_results(&b, c->stream);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->res, c->b_res.p, sizeof(DRes) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    collect_timers(c);
+    c->meta_stale = true;
+    c->cert_done = true;
+    return PHX_OK;
+}
+
 int phx_certified(phx_ctx *c, int8_t *cert) {
     if (!c || (!cert && c->n > 0)) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
+    { const int rc = ensure_cert(c); if (rc) return rc; }
     for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; cert[i] = (int8_t)(!c->certify ? -1 : (m.status < 0 ? 1 : m.cert)); }
     return PHX_OK;
 }
@@ -1194,7 +1213,9 @@ static double host_contig_pstop(uint32_t gc, int L) {
     return Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg;
 }
 
+static int ensure_cert(phx_ctx *c);
 int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
+    if (c && c->ran && !c->in_flight) { const int rc_ = ensure_cert(c); if (rc_) return rc_; }
     TAP_PRE(c, contig);
     if (!out) return PHX_E_ARG;
     memset(out, 0, sizeof(*out));
