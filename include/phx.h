@@ -171,6 +171,8 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
  * CERT_TIGHT multiplies its error bounds by 2^36, so that ordinary inputs come out uncertified (tests of the host re-solve). */
 #define PHX_CREATE_NO_CERTIFY 32u
 #define PHX_CREATE_CERT_TIGHT 64u
+#define PHX_CREATE_POISON 256u    /* every device buffer the context allocates is filled with the byte 0xA5 first: the library must not depend on fresh memory being zero */
+#define PHX_CREATE_ONE_STREAM 512u /* no side streams: every kernel of a run on the context's one stream, in program order */
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);

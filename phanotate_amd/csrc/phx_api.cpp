@@ -97,6 +97,9 @@ struct phx_ctx {
     bool cert_done = false; // k_certify has run on the results the context holds
     double cert_scale = 1.0;
     bool cert_wide = false; // test switch: every contig through k_certify_wide
+    bool poison = false;    // test switch: new device buffers are filled with a byte pattern
+    bool one_stream = false; // test switch: the side streams are the main stream
+    bool learning = false;   // enqueue_run is sizing the buffers between the kernels (DCaps.flags bit 2)
     DevBuf b_tie;         // scratch of k_inorder; grows to what the contigs with equal-length alternative paths ask for
     int64_t tie_seen = 0; // largest DTotals.tie_need a run reported
     DevBuf b_ekey;        // phx_solve: rank of every edge in the caller's order
@@ -150,6 +153,9 @@ int ensure(phx_ctx *c, DevBuf &b, size_t bytes) {
     size_t want = bytes + bytes / 8 + 4096;
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
+    // test switch: fresh device memory is not zero once several processes share a GPU (they hand each other's freed pages around);
+    // a kernel that reads what nobody wrote shows with this, on a box of its own too
+    if (c->poison) HIPCHK(c, hipMemset(b.p, 0xA5, want));
     return PHX_OK;
 }
 void release(DevBuf &b) {
@@ -292,7 +298,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     k->win = std::min(cap_of(c->b_win, sizeof(DWin), 8), cap_of(c->b_wrole, sizeof(uint2) * WIN_ROLES, 8));
     k->edge = std::min(cap_of(c->b_esrc, 4, 1), cap_of(c->b_ew, 8, 1));
     k->limbs = limbs;
-    k->flags = (c->force_global_sssp ? 1 : 0) | (c->no_wave ? 2 : 0);
+    k->flags = (c->force_global_sssp ? 1 : 0) | (c->no_wave ? 2 : 0) | (c->learning ? 4 : 0);
 }
 
 void fill_batch(phx_ctx *c, DBatch *b) {
@@ -468,7 +474,7 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -489,6 +495,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
     c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
+    c->poison = (flags & PHX_CREATE_POISON) != 0;
     c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
     auto fail = [&](int code) { g_create_error = c->err; phx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return fail(PHX_E_NODEVICE); }
@@ -500,8 +507,11 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         c->own_stream = true;
     }
-    for (int a = 0; a < 4; a++)
-        if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
+    for (int a = 0; a < 4; a++) {
+        if (flags & PHX_CREATE_ONE_STREAM) { c->aux[a] = c->stream; c->one_stream = true; } // test switch: nothing runs side by side
+        else if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
+        if (hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+    }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
@@ -570,7 +580,7 @@ void phx_destroy(phx_ctx *c) {
     c->res = nullptr; c->res_cap = 0;
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    for (int a = 0; a < 4; a++) { if (c->aux[a]) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
+    for (int a = 0; a < 4; a++) { if (c->aux[a] && !c->one_stream) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
     if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
@@ -737,6 +747,10 @@ const int kRetry = 1000; // run_once: a buffer was too small for this batch (or 
 // into a HIP graph).  mask / lds: solver classes launched and the LDS given to k_sssp_lds per limb class.
 int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     int rc;
+    // (sizing mode: the layout kernels do not flag totals beyond the capacities, the host reads the totals and grows the buffers;
+    //  until round 3 they did and the host cleared the flag with a 4-byte hipMemsetAsync between the kernels — which later
+    //  kernels did not always see when several processes shared the GPU: they skipped their work on a context's first run)
+    struct Learning { phx_ctx *c; Learning(phx_ctx *c_, bool on) : c(c_) { c->learning = on; } ~Learning() { c->learning = false; } } learning_scope(c, learn);
     const int n = c->n;
     hipStream_t s = c->stream;
     DBatch b;
@@ -789,7 +803,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         const size_t NW = NV / 16 + 8 * (size_t)n + 16; // window records of k_sssp_wave, see k_layout1
         if ((rc = ensure(c, c->b_win, NW * sizeof(DWin)))) return rc;
         if ((rc = ensure(c, c->b_wrole, NW * sizeof(uint2) * WIN_ROLES))) return rc;
-        HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s)); // the offsets stand; the capacities are now sufficient
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
@@ -813,7 +826,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_ew, (size_t)(ht->edge + 1) * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, ((size_t)ht->node + 8) * 8 * (size_t)c->n_limbs))) return rc;
         if (c->certify && (rc = ensure(c, c->b_csig, ((size_t)ht->node + 8) * 16 * (size_t)c->n_limbs))) return rc;
-        HIPCHK(c, hipMemsetAsync(&((DTotals *)c->b_tot.p)->overflow, 0, sizeof(int32_t), s));
         mask = ht->class_mask;
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
     }
@@ -1431,7 +1443,11 @@ int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
             bool same = (esrci[e] & 0x7fffffffu) == esrc[e];
             if (wide) { long long bits; memcpy(&bits, &t, 8); same = same && ((x | (1ll << 62)) == bits); }
             else same = same && std::fabs(t) < 4611686018427387904.0 && (long long)t == x;
-            if (!same) { c->err = "edge tap: recomputed weight differs from the solver's integer"; return PHX_E_STATE; }
+            if (!same) {
+                char msg[256];
+                snprintf(msg, sizeof(msg), "edge tap: recomputed weight differs from the solver's integer (contig %d edge %u: w %.17g, record %016llx, sources %u / %u)", contig, e, ew[e], (unsigned long long)x, esrci[e], esrc[e]);
+                c->err = msg; return PHX_E_STATE;
+            }
             out[e].inexact = (int32_t)(esrci[e] >> 31);
         }
     return PHX_OK;

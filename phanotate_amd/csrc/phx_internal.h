@@ -209,7 +209,8 @@ struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
     int64_t win;                      // window records (and WIN_ROLES lane records each)
     int32_t limbs;                    // 64-bit words per node in `dist`
-    int32_t flags;                    // bit 0: force the global-memory solver, bit 1: keep contigs off the wavefront kernel
+    int32_t flags;                    // bit 0: force the global-memory solver, bit 1: keep contigs off the wavefront kernel, bit 2: the host sizes the
+                                      //   buffers after each layout kernel (first run of a context): totals beyond the capacities are no overflow
 };
 
 struct DBatch {

@@ -53,6 +53,39 @@ def test_config5_eight_ranks_on_one_gpu_equal_one_process_and_the_oracle(tmp_pat
         np.testing.assert_allclose(g["score"], o["gene_score"], rtol=1e-9)
 
 
+FIRST_RUN_WORKER = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import phanotate_amd as pa
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+seqs = [pa.synth_contig(i, 50000) for i in range(rank, 8000, world)]
+ann = pa.Annotator(device=0)
+ann.upload(seqs); ann.run()
+first = ann.download_flat(exact=False)
+cert = ann.certified()
+for i in range(0, len(seqs), 40):
+    ann.edges(i)  # the tap checks the solver's integer edge records against the recomputed fp64 weights
+ann.run()
+second = ann.download_flat(exact=False)
+assert all(a.tobytes() == b.tobytes() for a, b in zip(first, second)), "rank %%d: the first run of the context differs from its second" %% rank
+assert (first[0] == 0).all() and (cert == 1).sum() >= len(seqs) - 2
+print("FIRST_RUN_OK", rank, flush=True)
+"""
+
+
+def test_first_run_of_a_context_with_eight_processes_on_one_gpu(tmp_path):
+    """A context's first run sizes its buffers between the kernels.  Until round 3 it cleared a device flag from the host in
+    between (hipMemsetAsync of 4 bytes), which later kernels did not always see once several processes shared the GPU: about one
+    process in ten came back with unreachable targets and shifted edge rows on its first batch — found by k_certify and the edge
+    tap, invisible on a box of its own.  Eight processes, 1000 contigs each, twice."""
+    script = tmp_path / "first_run.py"
+    script.write_text(FIRST_RUN_WORKER % ROOT)
+    for trial in range(2):
+        r = _torchrun(8, 29556 + trial, str(script), timeout=900)
+        assert r.stdout.count("FIRST_RUN_OK") == 8, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_rccl_plus_gloo_group_comes_up_with_one_rank():
     """shard.init_group's production branch ("cpu:gloo,cuda:nccl", device bound): barrier and all_reduce on the GPU over RCCL, the
     gather over gloo — with the single rank a 1-GPU box allows."""
