@@ -1155,7 +1155,7 @@ def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
     import ctypes as C
     from phanotate_amd import _lib
     h = C.c_void_p()
-    assert _lib.lib().phx_create_ex(C.byref(pa.make_params()), 0, None, 1 << 9, C.byref(h)) == -1  # unknown flag
+    assert _lib.lib().phx_create_ex(C.byref(pa.make_params()), 0, None, 1 << 20, C.byref(h)) == -1  # unknown flag
 
 
 def test_trna_hit_outside_the_contig_fails_that_contig_only(pa, oracle):
