@@ -48,8 +48,8 @@ extern "C" {
 #define PHX_S_BADTRNA (-4)   /* phx_set_trnas: a hit of this contig has an end outside 1..L (no node can be placed there) */
 #define PHX_S_PARALLEL (-6)  /* a bridge edge duplicates a connect edge [ValueError, graphs.py:74] */
 #define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit) */
-#define PHX_S_LONGORF (-8)   /* an ORF of more than 65535 codons (196 kb without an in-frame stop, e.g. a scaffold's N run): the per-ORF
-                              * GC-frame class counters are 16 bit.  [the reference has no such limit] */
+#define PHX_S_LONGORF (-8)   /* (no longer produced: until 0.3.0 an ORF of more than 65535 codons — 196 kb without an in-frame stop, a scaffold's N run —
+                              * overflowed the 16-bit class counters; such ORFs are now counted in 32 bits, functions.py:286-298 has no limit) */
 #define PHX_S_NEGCYCLE (-9)  /* relaxation did not converge in V rounds */
 #define PHX_S_NOPATH 1       /* warning: target unreachable from source; 0 genes reported */
 

@@ -1339,6 +1339,7 @@ int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
     reference_order(grp, order, ref_rank, ref_first);
     phx_globals gl;
     phx_tap_globals(c, contig, &gl);
+    std::vector<uint64_t> wide_bits;
     size_t k = 0;
     for (size_t rr = 0; rr < order.size(); rr++) {
         const DGrp &G = grp[(size_t)order[rr]];
@@ -1349,8 +1350,28 @@ int phx_tap_orfs(phx_ctx *c, int32_t contig, phx_orf *out) {
             o.start = r.start; o.stop = r.stop; o.frame = r.frame;
             o.length = r.frame > 0 ? r.stop + 2 - r.start + 1 : r.start + 2 - r.stop + 1;
             o.rbs = rs.rbs; o.startidx = rs.startidx; o.group = (int32_t)rr;
+            uint32_t h[9];
+            for (int i = 0; i < 9; i++) h[i] = rs.hist[i];
+            if (rs.flags & 4u) { // more than 65535 codons: the 16-bit record is clipped (k_score counted again); the tap counts on the host
+                if (wide_bits.empty()) {
+                    wide_bits.resize((size_t)PHX_BITMAP_WORDS_PER_NW * (size_t)m.nw);
+                    HIPCHK(c, hipMemcpy(wide_bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, wide_bits.size() * 8, hipMemcpyDeviceToHost));
+                }
+                const bool fwd = r.frame > 0;
+                const int f = (fwd ? r.frame : -r.frame) - 1;
+                const int lo1 = fwd ? r.start : r.stop, hi1 = (fwd ? r.stop : r.start) + 2, ncod = (hi1 - lo1 + 1) / 3;
+                const int k0 = (lo1 - 1 - f) / 3, k1 = k0 + ncod - 1, clo = fwd ? k0 : k0 + 1, chi = fwd ? k1 - 1 : k1;
+                const size_t nw = (size_t)m.nw;
+                const uint64_t *A = wide_bits.data() + ((size_t)((fwd ? PHX_PLANE_GCF : PHX_PLANE_GCR) * 3 + f)) * nw, *B = A + 3 * nw, *Cc = A + 6 * nw;
+                for (int i = 0; i < 9; i++) h[i] = 0;
+                for (int k = clo; k <= chi; k++) {
+                    const int a = (int)((A[k >> 6] >> (k & 63)) & 1), bb = (int)((B[k >> 6] >> (k & 63)) & 1), cc = (int)((Cc[k >> 6] >> (k & 63)) & 1);
+                    const int mx = (a && cc) ? 0 : ((!a && bb) ? 1 : 2), mn = (!a && !cc) ? 0 : ((a && !bb) ? 1 : 2); // gc_frame_plot.py:7-28
+                    h[mx * 3 + mn]++;
+                }
+            }
             double S = 0;
-            for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = rs.hist[a * 3 + cc]; S += (double)rs.hist[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
+            for (int a = 0; a < 3; a++) for (int cc = 0; cc < 3; cc++) { o.hist[a * 3 + cc] = (int32_t)h[a * 3 + cc]; S += (double)h[a * 3 + cc] * (gl.pos_max[a + 1] * gl.pos_min[cc + 1]); }
             o.S = S;
             o.pstop = rs.pstop;
             o.weight_rbs = gl.training_rbs[rs.rbs] / gl.background_rbs[rs.rbs];

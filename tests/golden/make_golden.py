@@ -316,6 +316,9 @@ def main():
     gapseq = "".join("tagctaactgattaa"[i % 15] for i in range(900))
     cases.append(("edge_bridge", "edge_bridge", lam[1000:4000] + gapseq + lam[4000:7000], {}))
     cases.append(("edge_bridge_left", "edge_bridge_left", gapseq + lam[4000:8000], {}))
+    # an N run of 197 kb inside a contig: reading frames without a stop over 65 667 codons (the reference loops over any length,
+    # functions.py:286-298; libphx keeps per-ORF class counts in 16 bits and counts such ORFs again in 32: VERDICT r2 #8)
+    cases.append(("edge_longorf", "edge_longorf", synth(300, 8000) + "n" * 197000 + synth(301, 8000), {}))
     # non-default flags (file_handling.py:51-53)
     cases.append(("param_minlen60", "param_minlen60", synth(200, 6000), dict(minlen=60)))
     cases.append(("param_codons", "param_codons", synth(201, 6000), dict(start_codons="atg:0.7,gtg:0.2,ttg:0.05,ctg:0.05", stop_codons="tag,taa")))
