@@ -257,6 +257,9 @@ struct DBatch {
     uint2 *wrole;       //   WIN_ROLES lane records per window
     int32_t *olist;     // per contig V-1 node ids: open nodes, the target, close nodes (k_node_order -> k_edges)
     uint64_t *ehit;     // per node: verdicts of its first 64 overlap-edge candidates (k_edges<false> -> k_edges<true>)
+    uint32_t *mreach;   // per node, 4 x node capacity: the lowest node an overlap (backward) edge out of this close node ends in (0xffffffff: none).
+                        //   k_node_attr presets, k_edges<false> fills three partial arrays (see there), k_edges_scan leaves their minimum in the
+                        //   first: k_wave_plan watches a close node only where that reaches into the final part, k_sssp_wave steps back to it
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
