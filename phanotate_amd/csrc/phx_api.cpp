@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,6 +60,49 @@ struct MetaBuf {
 
 } // namespace
 
+// Worker threads that pack the letters of phx_upload (created at the first batch large enough to need them, kept until phx_destroy:
+// starting a thread costs as much as packing a megabase).
+struct StagePool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void()> *job = nullptr;
+    uint64_t gen = 0;
+    int active = 0;
+    bool stop = false;
+    void grow(int n) {
+        while ((int)th.size() < n) {
+            try { th.emplace_back([this, seen = gen]() mutable { loop(seen); }); } catch (...) { break; }
+        }
+    }
+    void loop(uint64_t seen) {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void()> *j = job;
+            lk.unlock();
+            (*j)();
+            lk.lock();
+            if (--active == 0) cv_done.notify_all();
+        }
+    }
+    void start(const std::function<void()> *j) { // every worker runs *j once; `finish` returns when all have
+        std::lock_guard<std::mutex> lk(m);
+        job = j; active = (int)th.size(); gen++;
+        cv.notify_all();
+    }
+    void finish() {
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
+    ~StagePool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; cv.notify_all(); }
+        for (std::thread &t : th) t.join();
+    }
+};
+
 struct phx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -82,6 +128,9 @@ struct phx_ctx {
     size_t res_cap = 0;
     std::vector<DTile> tiles;
     const void *attached = nullptr;
+    bool packed = false;     // b_ascii holds nibbles (phx_upload), not letters (phx_attach)
+    hipEvent_t ev_upload = nullptr; bool upload_pending = false; // recorded behind the last copy of phx_upload
+    std::unique_ptr<StagePool> pool;
     // buffers
     DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_owi, b_oflag, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
     DevBuf b_ewf, b_esrcf;   // fp64 weights and plain sources of the batch last run, recomputed for the edge tap (k_edges<true, true>)
@@ -315,6 +364,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->params = c->d_params;
     b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
     b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
+    b->packed = c->packed ? 1 : 0;
     b->rbs = (uint16_t *)c->b_rbs.p;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p; b->iprev = (int32_t *)c->b_iprev.p;
@@ -514,6 +564,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
         else if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         if (hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     }
+    if (hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
@@ -583,6 +634,7 @@ void phx_destroy(phx_ctx *c) {
     collect_timers(c);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int a = 0; a < 4; a++) { if (c->aux[a] && !c->one_stream) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
     if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
@@ -597,10 +649,14 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     if (!c || n < 0 || (n > 0 && (!seq || !len))) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->in_flight) (void)settle(c); // a run still in flight reads the buffers this call replaces
+    if (c->upload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; } // the previous batch's copies read the staging memory
     c->attached = nullptr;
+    c->packed = true;
     int rc = set_batch_layout(c, n, len, nullptr);
     if (rc) return rc;
-    const size_t T = (size_t)c->totalL + 64;
+    // The letters cross the link as nibbles (phx_pack_bases: base code, "not acgt", "outside the alphabet"; rows stay 16-base aligned,
+    // so a row starts at byte off / 2): the staging pass has to touch every letter anyway and writes — and PCIe moves — half the bytes.
+    const size_t T = ((size_t)c->totalL + 1) / 2 + 64;
     if ((rc = ensure(c, c->b_ascii, T))) return rc;
     if (c->h_stage_cap < T) {
         if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
@@ -608,53 +664,72 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         HIPCHK(c, hipHostMalloc(&c->h_stage, T + T / 8, hipHostMallocDefault));
         c->h_stage_cap = T + T / 8;
     }
-    // Stage into pinned memory and send in pieces of >= 4 MB (whole contigs), so that the DMA of one piece overlaps the staging
-    // of the next.  One host thread copies 50 MB in ~2 ms while the link moves it in ~0.9 ms: large batches are staged by a few
-    // worker threads, the calling thread enqueues each piece as soon as it is complete (in order).
+    // Packed into pinned memory and sent in pieces of >= 4 Mbases (whole contigs; 2 MB copies reach ~45 of the link's 56 GB/s), so
+    // that the DMA of one piece overlaps the packing of the next.  Large batches are packed by the context's worker threads, all of
+    // them on the earliest unfinished piece (items of <= 128 Kbases, taken in order), so that the first copy starts after 1/threads
+    // of a piece's packing time; the calling thread enqueues each piece as soon as its last item is done.
     StageTimer t(c, ST_COPY);
-    struct Piece { int i0, i1; int64_t beg, end; };
+    struct Piece { int i0, i1; int64_t beg, end; int items; };
+    struct Item { const char *in; int64_t n; uint8_t *out; int piece; };
     std::vector<Piece> pieces;
+    std::vector<Item> items;
     {
-        const int64_t piece = 4 << 20;
+        const int64_t piece = 4 << 20, chunk = 128 << 10;
         int64_t sent = 0; int first = 0;
         for (int i = 0; i < n; i++) {
-            const int64_t end = i + 1 < n ? c->meta[(size_t)i + 1].off : c->totalL; // rows are 16-byte aligned: the gap belongs to the piece
-            if (end - sent >= piece || i + 1 == n) { pieces.push_back(Piece{first, i + 1, sent, end}); sent = end; first = i + 1; }
+            const int64_t end = i + 1 < n ? c->meta[(size_t)i + 1].off : c->totalL; // rows are 16-base aligned: the gap belongs to the piece
+            uint8_t *row = (uint8_t *)c->h_stage + (c->meta[(size_t)i].off >> 1);
+            for (int64_t o = 0; o < len[i]; o += chunk) items.push_back(Item{seq[i] + o, std::min(chunk, len[i] - o), row + (o >> 1), (int)pieces.size()});
+            if (end - sent >= piece || i + 1 == n) {
+                int cnt = 0;
+                for (size_t k = items.size(); k > 0 && items[k - 1].piece == (int)pieces.size(); k--) cnt++;
+                pieces.push_back(Piece{first, i + 1, sent, end, cnt}); sent = end; first = i + 1;
+            }
         }
     }
-    auto stage_piece = [&](const Piece &pc) {
-        for (int i = pc.i0; i < pc.i1; i++) memcpy((char *)c->h_stage + c->meta[(size_t)i].off, seq[i], (size_t)len[i]);
+    auto send_piece = [&](const Piece &pc) { // [beg, end) in bases -> bytes (piece boundaries are row starts: even)
+        const size_t b0 = (size_t)(pc.beg >> 1), b1 = (size_t)((pc.end + 1) >> 1);
+        return hipMemcpyAsync((char *)c->b_ascii.p + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream);
     };
-    const int np = (int)pieces.size();
-    const int nthreads = np >= 3 ? std::min(4, np) : 0;
+    const int np = (int)pieces.size(), ni = (int)items.size();
+    int nthreads = 0;
+    if (c->totalL >= (2 << 20)) {
+        const int hw = (int)std::thread::hardware_concurrency();
+        nthreads = std::min(std::max(1, ni / 4), std::max(1, std::min(16, hw / 4)));
+        if (!c->pool) c->pool.reset(new (std::nothrow) StagePool());
+        if (c->pool) c->pool->grow(nthreads);
+        nthreads = c->pool ? (int)c->pool->th.size() : 0; // no thread to be had: the calling thread packs everything
+    }
     if (nthreads == 0) {
+        int k = 0;
         for (const Piece &pc : pieces) {
-            stage_piece(pc);
-            HIPCHK(c, hipMemcpyAsync((char *)c->b_ascii.p + pc.beg, (char *)c->h_stage + pc.beg, (size_t)(pc.end - pc.beg), hipMemcpyHostToDevice, c->stream));
+            for (int e = k + pc.items; k < e; k++) phx_pack_bases(items[(size_t)k].in, items[(size_t)k].n, items[(size_t)k].out);
+            HIPCHK(c, send_piece(pc));
         }
     } else {
         std::atomic<int> next(0);
-        std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[(size_t)np]);
-        for (int k = 0; k < np; k++) done[(size_t)k].store(0, std::memory_order_relaxed);
-        std::vector<std::thread> workers;
-        auto work = [&]() {
-            for (int k; (k = next.fetch_add(1)) < np;) { stage_piece(pieces[(size_t)k]); done[(size_t)k].store(1, std::memory_order_release); }
+        std::unique_ptr<std::atomic<int>[]> left(new std::atomic<int>[(size_t)np]); // items of the piece not packed yet
+        for (int k = 0; k < np; k++) left[(size_t)k].store(pieces[(size_t)k].items, std::memory_order_relaxed);
+        const std::function<void()> work = [&]() {
+            for (int k; (k = next.fetch_add(1)) < ni;) {
+                const Item &it = items[(size_t)k];
+                phx_pack_bases(it.in, it.n, it.out);
+                left[(size_t)it.piece].fetch_sub(1, std::memory_order_acq_rel);
+            }
         };
-        for (int w = 0; w < nthreads; w++) {
-            try { workers.emplace_back(work); } catch (...) { break; } // no thread to be had: the calling thread stages what is left
-        }
-        if (workers.empty()) work();
+        c->pool->start(&work);
         hipError_t err = hipSuccess;
         for (int k = 0; k < np; k++) {
-            while (!done[(size_t)k].load(std::memory_order_acquire)) std::this_thread::yield();
-            const Piece &pc = pieces[(size_t)k];
-            if (err == hipSuccess)
-                err = hipMemcpyAsync((char *)c->b_ascii.p + pc.beg, (char *)c->h_stage + pc.beg, (size_t)(pc.end - pc.beg), hipMemcpyHostToDevice, c->stream);
+            while (left[(size_t)k].load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            if (err == hipSuccess) err = send_piece(pieces[(size_t)k]);
         }
-        for (std::thread &th : workers) th.join();
+        c->pool->finish(); // (the workers hold references to this frame)
         HIPCHK(c, err);
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // No wait here: the letters are staged (the caller's strings are free again), the copies are ordered before the run on the
+    // context's stream, and the next phx_upload waits for this event before it touches the staging memory.
+    HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
+    c->upload_pending = true;
     c->uploaded = true;
     return PHX_OK;
 }
@@ -730,6 +805,7 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
     int rc = set_batch_layout(c, n, nullptr, offsets);
     if (rc) return rc;
     c->attached = d_ascii;
+    c->packed = false; // the caller's letters as they are
     c->uploaded = true;
     return PHX_OK;
 }
@@ -1272,7 +1348,12 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
         std::vector<uint8_t> asc(L);
         if (nw) HIPCHK(c, hipMemcpy(bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, bits.size() * 8, hipMemcpyDeviceToHost));
         if (L) HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));
-        if (L) HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
+        if (L && !c->packed) HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
+        if (L && c->packed) { // nibbles: back to a letter per position (what is not one of acgt reads as 'n' here)
+            std::vector<uint8_t> pk((L + 1) / 2);
+            HIPCHK(c, hipMemcpy(pk.data(), (const uint8_t *)c->b_ascii.p + (m.off >> 1), pk.size(), hipMemcpyDeviceToHost));
+            for (size_t p = 0; p < L; p++) { const unsigned nb = (pk[p >> 1] >> (4 * (p & 1))) & 15u; asc[p] = (nb & 4u) ? (uint8_t)'n' : (uint8_t)"actg"[nb & 3u]; }
+        }
         DParams dp;
         build_dparams(&c->params, &dp);
         auto code = [](uint8_t ch) -> int { switch (ch | 0x20) { case 'a': return 0; case 'c': return 1; case 't': return 2; case 'g': return 3; default: return -1; } };

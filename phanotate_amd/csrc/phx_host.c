@@ -19,6 +19,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <immintrin.h>
+
 #include "../../include/phx.h"
 
 struct phx_fasta {
@@ -327,3 +329,50 @@ int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *gene
 }
 
 void phx_free_text(char *text) { free(text); }
+
+/* ---- bases packed for the link (phx_upload): one nibble per letter, two per byte, low nibble first ----
+ * bits 0-1 base code a0 c1 t2 g3 — for an ambiguity code the base the reference counts it as (s, b, v -> g; the others -> a,
+ * functions.py:159-163) —, bit 2 = not one of acgt, bit 3 = a letter outside acgtnryswkmbvdh (KeyError in rev_comp,
+ * functions.py:20-24); any case (functions.py:144).  k_features decodes the nibbles; half the bytes cross PCIe, and the staging
+ * pass that has to touch every letter anyway writes half as much. */
+static const uint8_t kNib[32] = {12, 0, 7, 1, 4, 12, 12, 3, 4, 12, 12, 4, 12, 4, 4, 12, /* ` a b c d e f g h i j k l m n o */
+                                 12, 12, 4, 7, 2, 12, 7, 4, 12, 4, 12, 12, 12, 12, 12, 12}; /* p q r s t u v w x y z { | } ~ DEL */
+static inline uint8_t nib_of(uint8_t ch) {
+    const uint8_t x = (uint8_t)(ch | 0x20u);
+    return (x & 0xe0u) == 0x60u ? kNib[x & 31u] : (uint8_t)12; /* ('@' and '[' .. '_' land on entries that are not letters) */
+}
+static void pack_scalar(const uint8_t *in, size_t n, uint8_t *out) {
+    size_t i = 0;
+    for (; i + 1 < n; i += 2) out[i >> 1] = (uint8_t)(nib_of(in[i]) | (nib_of(in[i + 1]) << 4));
+    if (i < n) out[i >> 1] = nib_of(in[i]);
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void pack_avx2(const uint8_t *in, size_t n, uint8_t *out) {
+    const __m256i lut_lo = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)kNib));
+    const __m256i lut_hi = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)(kNib + 16)));
+    const __m256i c20 = _mm256_set1_epi8(0x20), c1f = _mm256_set1_epi8(0x1f), ce0 = _mm256_set1_epi8((char)0xe0), c60 = _mm256_set1_epi8(0x60),
+                  c10 = _mm256_set1_epi8(0x10), cbad = _mm256_set1_epi8(12), cmul = _mm256_set1_epi16(0x1001);
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i x = _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(in + i)), c20);
+        const __m256i v = _mm256_and_si256(x, c1f);
+        const __m256i lo = _mm256_shuffle_epi8(lut_lo, v), hi = _mm256_shuffle_epi8(lut_hi, v);
+        __m256i nb = _mm256_blendv_epi8(lo, hi, _mm256_cmpeq_epi8(_mm256_and_si256(v, c10), c10));
+        nb = _mm256_blendv_epi8(cbad, nb, _mm256_cmpeq_epi8(_mm256_and_si256(x, ce0), c60));
+        const __m256i w = _mm256_maddubs_epi16(nb, cmul);             /* per pair: even letter + 16 * odd letter */
+        const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(w, w), 0xd8);
+        _mm_storeu_si128((__m128i *)(out + (i >> 1)), _mm256_castsi256_si128(pk));
+    }
+    if (i < n) pack_scalar(in + i, n - i, out + (i >> 1)); /* (i is even) */
+}
+#endif
+/* n letters -> (n + 1) / 2 bytes */
+void phx_pack_bases(const char *in, int64_t n, uint8_t *out) {
+    if (n <= 0) return;
+#if defined(__x86_64__)
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+    if (have) { pack_avx2((const uint8_t *)in, (size_t)n, out); return; }
+#endif
+    pack_scalar((const uint8_t *)in, (size_t)n, out);
+}

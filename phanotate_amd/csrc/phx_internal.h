@@ -225,7 +225,10 @@ struct DBatch {
     const DParams *params;
     const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;
     // per position
-    const uint8_t *ascii;
+    const uint8_t *ascii; // the bases: one ASCII letter per position (phx_attach), or — packed != 0, phx_upload — one nibble per position, two per
+                          //   byte (low nibble first): bits 0-1 base code a0 c1 t2 g3 (for an ambiguity code the base it counts as, functions.py:159-163),
+                          //   bit 2 = not one of acgt, bit 3 = a letter outside the IUPAC alphabet; a contig's row starts at byte off / 2
+    int32_t packed;
     uint16_t *rbs;
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
@@ -286,6 +289,7 @@ struct DBatch {
 #ifdef __cplusplus
 extern "C" {
 #endif
+void phx_pack_bases(const char *in, int64_t n, uint8_t *out); // phx_host.c: letters -> nibbles (DBatch.ascii with packed != 0)
 // kernel launchers (phx_kernels.hip); all asynchronous on `stream`
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream);
 void phxk_orf_count(const DBatch *b, void *stream);
