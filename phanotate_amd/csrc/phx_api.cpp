@@ -1535,17 +1535,18 @@ int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
     HIPCHK(c, hipMemcpy(in_off.data(), (uint32_t *)c->b_inoff.p + m.node_off + contig, (V + 1) * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(esrc.data(), (uint32_t *)c->b_esrcf.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(ew.data(), (double *)c->b_ewf.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
-    // the records the solver read: source | inexact << 31, and the integer trunc(w * 1000) in the encoding of ew_encode
+    // the records the solver read: source | off-path << 30 | inexact << 31, and the integer trunc(w * 1000) in the encoding of ew_encode
     HIPCHK(c, hipMemcpy(esrci.data(), (uint32_t *)c->b_esrc.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(ewi.data(), (long long *)c->b_ew.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
     for (size_t v = 0; v < V; v++)
         for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) {
+            esrc[e] = ESRC_NODE(esrc[e]); // (the tap variant carries the off-path flag of a source-node edge)
             out[e].src = (int32_t)esrc[e]; out[e].dst = (int32_t)v; out[e].w = ew[e];
             // the tap's weight and the solver's integer are two results of one computation: any difference is an error of the library
             const double t = std::trunc(ew[e] * 1000.0);
             const long long x = ewi[e];
             const bool wide = (((unsigned long long)x >> 63) ^ ((unsigned long long)x >> 62)) & 1ull;
-            bool same = (esrci[e] & 0x7fffffffu) == esrc[e];
+            bool same = ESRC_NODE(esrci[e]) == esrc[e];
             if (wide) { long long bits; memcpy(&bits, &t, 8); same = same && ((x | (1ll << 62)) == bits); }
             else same = same && std::fabs(t) < 4611686018427387904.0 && (long long)t == x;
             if (!same) {

@@ -43,8 +43,11 @@ static_assert((RBS_CLS0 | RBS_CLS1 | RBS_CLS2 | RBS_CLS3) == 0x0ffffffeu && (RBS
 #define CLS_RT 4 // rev_comp(codon) in stop_codons
 // cls byte (DParams.cls_tab, the cls tap; no per-position array on the device): bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
 
-#define ESRC_NODE(x) ((x) & 0x7fffffffu)
+#define ESRC_NODE(x) ((x) & 0x3fffffffu)
 #define ESRC_INEXACT(x) ((x) >> 31)
+#define ESRC_OFFPATH(x) (((x) >> 30) & 1u) // not for k_sssp_wave's common path: |W| >= 2^51, or the edge leaves the source node
+#define ESRC_F_INEXACT 0x80000000u
+#define ESRC_F_OFFPATH 0x40000000u
 
 // node link word: bits 30-31 kind, bits 0-29 index
 #define LINK_NONE 0u
@@ -247,7 +250,7 @@ struct DBatch {
     DOrfStat *ostat;    // k_orf_stats -> k_score, k_node_attr
     double *oweight;    // Orf.weight: k_score -> genes (and the tap variant of k_edges)
     long long *owi;     // the same as the solver's integer (ew_encode) and
-    uint8_t *oflag;     //   its inexact flag: k_score -> k_edges
+    uint8_t *oflag;     //   its flags: bit 0 |W| >= 2^51, bit 1 inexact (k_score -> k_edges: bits 30 and 31 of esrc)
     int32_t *onode;     // device node id of the ORF's start node: k_node_build -> k_edges
     DGrp *grp;
     // per node
@@ -266,7 +269,7 @@ struct DBatch {
     uint64_t *dist;
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
-    uint32_t *esrc;     // source node | inexact << 31 (ESRC_NODE / ESRC_INEXACT)
+    uint32_t *esrc;     // source node | off-path << 30 | inexact << 31 (ESRC_NODE / ESRC_OFFPATH / ESRC_INEXACT)
     long long *ew;      // integer weight, encoded (ew_encode / ew_decode)
     uint32_t *esrcf;    // tap variant of k_edges<true> only: plain source nodes and
     double *ewf;        //   fp64 weights, into scratch of their own

@@ -108,7 +108,9 @@ __device__ __forceinline__ uint64_t row16_sum_u64(uint64_t x, int sub) {
 //   ew: the integer the solver works on, W = trunc(w * 1000) (edges.py:22), so that no consumer converts fp64 again: a value with
 //       |W| < 2^62 as it is (bits 63 and 62 equal); a wider one as the bit pattern of the double p = trunc(w * 1000) — whose bit 62 is
 //       always set, |p| >= 2^62 — with bit 62 forced to differ from bit 63, which marks it (ew_decode, phx_sssp.inc, restores it).
-//   esrc: source node in bits 0..30; bit 31 = "inexact": the reference's integer trunc(Decimal(w) * 1000) may differ from W
+//   esrc: source node in bits 0..29; bit 30 = "off the solver's common path": |W| >= 2^51 (its integer is not the low half of a narrow
+//       128-bit value) or the edge leaves the source node (whose distance has its own ring slot), so that k_sssp_wave tests one
+//       bit per in-edge; bit 31 = "inexact": the reference's integer trunc(Decimal(w) * 1000) may differ from W
 //       (k_certify's eps_e > 0, phx_certify.inc) — decided here, where the fp64 weight still exists.
 // The fp64 weights themselves are not kept: the taps recompute them (k_edges<true, true>).
 #define EW_WIDE(x) (((((unsigned long long)(x)) >> 63) ^ (((unsigned long long)(x)) >> 62)) & 1ull)
@@ -119,16 +121,17 @@ __device__ __forceinline__ long long ew_encode(double w) {
     const long long bits = __double_as_longlong(t);
     return bits < 0 ? (bits & ~(1ll << 62)) : bits;
 }
-// cert_eps(w) == 0 (phx_certify.inc): p = w * 1000 is farther from the next integer than its error bound err = |p| (|exponent| + 8)
-// 2^-46 x scale, so the reference's truncation cannot differ.  c = scale * 2^-46.
+__device__ __forceinline__ bool ew_narrow51(long long w) { return (unsigned long long)(w + (1ll << 51)) < (1ull << 52); }
+// cert_eps(w) == 0 (phx_certify.inc): p = w * 1000 is farther from the next integer than an upper bound of its error bound
+// |p| (|exponent| + 8) 2^-46 x scale — |exponent| + 8 <= 60 for 1/2 <= |p| < 2^52, and a |p| below 1/2 truncates to 0 on both sides
+// whatever its exponent —, so the reference's truncation cannot differ.  c = scale * 2^-46.
 __device__ __forceinline__ bool cert_eps_is_zero_fast(double w, double c) {
+#ifdef EW_NOCHECK
+    return true;
+#endif
     const double p = w * 1000.0, a = fabs(p);
-    const int ef = (int)(((uint32_t)((unsigned long long)__double_as_longlong(a) >> 52)) & 0x7ffu);
-    int ex = ef - 1022; // frexp's exponent of a normal number (a == 0: no error either way; subnormal weights do not occur)
-    ex = a > 0.0 ? (ex < 0 ? -ex : ex) : 0;
-    const double err = a * (double)(ex + 8) * c;
-    const double f = a - floor(a);
-    const bool far = (f < 1.0 - f ? f : 1.0 - f) > err;
+    const double f = a - fabs(trunc(p));
+    const bool far = (f < 1.0 - f ? f : 1.0 - f) > a * (60.0 * c);
     return w == -20.0 || (a < 4503599627370496.0 && far);
 }
 #define CERT_C(b) ((b).cert_scale * 1.4210854715202004e-14) // 2^-46
@@ -138,7 +141,10 @@ template <bool TAPW>
 __device__ __forceinline__ EWt make_ew(double w, double c) {
     EWt r;
     if (TAPW) { r.bits = (unsigned long long)__double_as_longlong(w); r.fl = 0u; }
-    else { r.bits = (unsigned long long)ew_encode(w); r.fl = cert_eps_is_zero_fast(w, c) ? 0u : 0x80000000u; }
+    else {
+        r.bits = (unsigned long long)ew_encode(w);
+        r.fl = (cert_eps_is_zero_fast(w, c) ? 0u : ESRC_F_INEXACT) | (ew_narrow51((long long)r.bits) ? 0u : ESRC_F_OFFPATH);
+    }
     return r;
 }
 

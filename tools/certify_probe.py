@@ -44,11 +44,9 @@ def flag_of(w, scale=1.0):
         return 0  # the tRNA edge: a constant in the reference too (functions.py:509)
     p = w * 1000.0
     a = abs(p)
-    ex = abs(math.frexp(a)[1]) if a > 0 else 0
-    err = a * float(ex + 8) * (scale * 2.0 ** -46)
     if a < 2.0 ** 52:
-        f = a - math.floor(a)
-        if min(f, 1.0 - f) > err:
+        f = a - abs(float(math.trunc(p)))
+        if min(f, 1.0 - f) > a * (60.0 * (scale * 2.0 ** -46)):
             return 0
     return 1
 
