@@ -379,6 +379,8 @@ def main():
         balgo = algorithmic_bytes(sz)
         achieved = balgo / (dom_ms * 1e-3) / 1e9
         step_achieved = balgo / (kernel_ms_per_step * 1e-3) / 1e9
+        kern_of = [int(ann.globals(i).sssp_kernel) for i in range(len(seqs))]
+        solver_kernels = {"wavefront_tight": kern_of.count(2), "wavefront_roomy": kern_of.count(3), "workgroup": kern_of.count(1), "global": kern_of.count(0)}
         out = {
             "metric": "Mbp/s annotated (whole node) on 50 kb synthetic phage contigs" if args.workload == "synthetic" else "Mbp/s annotated, single contig",
             "value": round(value, 3),
@@ -403,6 +405,7 @@ def main():
                 "contigs_with_error_status": int((st_all < 0).sum()),
                 "int_limbs": int(ann.globals(0).n_limbs),
                 "solver_kernel_contig0": int(ann.globals(0).sssp_kernel),
+                "solver_kernels": solver_kernels,
             },
             "certificate": {"ms_per_step_with_run": round(dt_cert / args.steps * 1e3, 4), "ms_on_top_of_run": round((dt_cert - dt) / args.steps * 1e3, 4), "contigs_not_certified": n_uncert,
                             "what": "phx_run + phx_certified per step: k_certify proves per contig, in exact integers, that the gene list is the one the reference's Decimal-derived integers give (phx_certify.inc); computed on demand, so `value` does not contain it, `host_to_host` (Annotator.download_flat asks for it) does"},

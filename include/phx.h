@@ -128,7 +128,7 @@ typedef struct phx_globals {
     int32_t sssp_sweeps; /* outer sweeps of the device relaxation */
     int32_t sssp_iters;  /* relaxation rounds summed over all windows and sweeps */
     int32_t status;
-    int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig */
+    int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig, 3 the same in its roomy configuration */
     int32_t sssp_handed_back; /* != 0: the wavefront kernel passed the contig on: 1 a node's 500 bp neighbourhood exceeds a window,
                                * 2 spill list full, 3 no convergence, 4 too many step-backs */
     int32_t tie; /* equal-length alternatives to the shortest path (the reference's relaxation order decides, see phx_inorder.inc):

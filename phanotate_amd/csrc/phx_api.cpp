@@ -906,6 +906,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_dist, ((size_t)ht->node + 8) * 8 * (size_t)c->n_limbs))) return rc;
         if (c->certify && (rc = ensure(c, c->b_csig, ((size_t)ht->node + 8) * 16 * (size_t)c->n_limbs))) return rc;
         mask = ht->class_mask;
+        if (mask & 4) mask |= 8; // k_wave_plan (still to run) may move 128-bit contigs to the wavefront kernel's roomy configuration: this run launches it in any case
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
     }
     fill_batch(c, &b);
@@ -927,7 +928,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         const int nl_of[4] = {2, 4, 8, 17};
         int nlaunch = 0, nclass = 0;
         bool used[3] = {false, false, false};
-        for (int k = 0; k < 4; k++) nclass += ((mask >> (4 * k)) & 7) ? 1 : 0;
+        for (int k = 0; k < 4; k++) nclass += ((mask >> (4 * k)) & 15) ? 1 : 0;
         // contigs that never enter the wavefront kernel (too dense for its windows: k_edges<false>; a window the planner could not
         // lay out: k_wave_plan, which has finished by now) are solved by the workgroup kernel on a side stream, beside the
         // wavefront kernel; the launch after the wavefront kernel then only takes what that kernel handed back while it ran
@@ -944,14 +945,14 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
             HIPCHK(c, hipEventRecord(c->ev_join[2], c->aux[2]));
         }
         for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
-            if (!((mask >> (4 * k)) & 7)) continue;
+            if (!((mask >> (4 * k)) & 15)) continue;
             hipStream_t st = s;
             if (nlaunch > 0 && c->aux[0]) {
                 const int a = (nlaunch - 1) % 2;
                 if (!used[a]) { HIPCHK(c, hipStreamWaitEvent(c->aux[a], c->ev_fork, 0)); used[a] = true; }
                 st = c->aux[a];
             }
-            for (int mode = 2; mode >= 0; mode--)
+            for (int mode = 3; mode >= 0; mode--) // 3: the wavefront kernel's roomy configuration (few contigs, if any), 2: its tight one
                 if ((mask >> (4 * k + mode)) & 1) {
                     if (early && mode == 1 && early_k(k)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launch: it skips what that one solved
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
@@ -965,7 +966,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     {
         StageTimer t(c, ST_INORDER);
         int nlm = 0;
-        for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 7) ? 1 << k : 0;
+        for (int k = 0; k < 4; k++) nlm |= ((mask >> (4 * k)) & 15) ? 1 << k : 0;
         phxk_inorder(&b, nlm, s);
         if (b.gpack) phxk_gene_pack(&b, s);
     } // equal-length alternatives: the parents of the reference's relaxation order
@@ -1110,11 +1111,11 @@ static void dev_report(phx_ctx *c) {
     if (getenv("PHX_DEBUG_CENSUS")) { uint32_t t[4] = {0,0,0,0}; (void)hipMemcpy(t, c->b_gtot.p, 16, hipMemcpyDeviceToHost); fprintf(stderr, "census: max concurrent sssp workgroups %u (end %u)\n", t[2], t[1]); }
     if (getenv("PHX_DEBUG_WAVE")) {
         int nfb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nw = 0;
-        for (int i = 0; i < n; i++) { if (c->meta[i].sssp_mode == 2) nw++; else if (c->meta[i].n_node > 2 && c->meta[i].sssp_nl == 2) nfb[c->meta[i].sssp_why & 7]++; }
+        for (int i = 0; i < n; i++) { if (c->meta[i].sssp_mode == 2 || c->meta[i].sssp_mode == 3) nw++; else if (c->meta[i].n_node > 2 && c->meta[i].sssp_nl == 2) nfb[c->meta[i].sssp_why & 7]++; }
         fprintf(stderr, "wave kernel: %d contigs done, handed back: plan %d spill %d no-convergence %d rollbacks %d other %d\n", nw, nfb[1], nfb[2], nfb[3], nfb[4], nfb[0]);
         std::vector<std::pair<double, int>> tt;
         long nroll = 0;
-        for (int i = 0; i < n; i++) if (c->meta[i].sssp_mode == 2) { const DMeta &m = c->meta[i]; tt.push_back({(m.pmax[0] + m.pmax[1] + m.pmax[2] + m.pmax[3] + m.pmin[0] + m.pmin[1]) * 0.01, i}); nroll += m.sweeps - 1; }
+        for (int i = 0; i < n; i++) if (c->meta[i].sssp_mode == 2 || c->meta[i].sssp_mode == 3) { const DMeta &m = c->meta[i]; tt.push_back({(m.pmax[0] + m.pmax[1] + m.pmax[2] + m.pmax[3] + m.pmin[0] + m.pmin[1]) * 0.01, i}); nroll += m.sweeps - 1; }
         std::sort(tt.begin(), tt.end());
         if (!tt.empty()) {
             const DMeta &m = c->meta[tt.back().second];
@@ -1249,7 +1250,7 @@ static int ensure_cert(phx_ctx *c) {
     DBatch b;
     fill_batch(c, &b);
     int nlm = 0;
-    for (int k = 0; k < 4; k++) nlm |= ((c->last_mask >> (4 * k)) & 7) ? 1 << k : 0;
+    for (int k = 0; k < 4; k++) nlm |= ((c->last_mask >> (4 * k)) & 15) ? 1 << k : 0;
     {
         StageTimer t(c, ST_CERTIFY);
         phxk_certify(&b, nlm, c->cert_wide ? -1 : c->last_vmax, c->stream);

@@ -277,24 +277,30 @@ int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
 // (may) hold 256-bit contigs for the wavefront kernel, whose lanes keep fewer in-edges
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
-    hipLaunchKernelGGL(k_wave_plan<2>, dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
-    if (wide_too) hipLaunchKernelGGL(k_wave_plan<4>, dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL((k_wave_plan<2, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b); // the contigs the tight configuration could not take
+    if (wide_too) hipLaunchKernelGGL((k_wave_plan<4, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
 }
 
 // mode 0: global-memory kernel (+ k_path); mode 1: workgroup-per-contig LDS kernel with `lds_bytes` of dynamic LDS;
-// mode 2: wavefront-per-contig kernel (contigs it hands back carry their fallback mode in sssp_mode afterwards)
+// mode 2: wavefront-per-contig kernel (contigs it hands back carry their fallback mode in sssp_mode afterwards); mode 3: the same
+// kernel in its roomy configuration (128-bit contigs that k_wave_plan could not lay out in the tight one)
 void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream) {
     dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 2) {
-        if (nl == 2) {
-            const size_t lb = wv_lds_bytes<2>();
-            (void)hipFuncSetAttribute((const void *)k_sssp_wave<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            hipLaunchKernelGGL(k_sssp_wave<2>, g, dim3(64), lb, s, *b);
+    if (mode == 2 || mode == 3) {
+        if (nl == 2 && mode == 2) {
+            const size_t lb = wv_lds_bytes<2, 0>();
+            (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((k_sssp_wave<2, 0>), g, dim3(64), lb, s, *b);
+        } else if (nl == 2) {
+            const size_t lb = wv_lds_bytes<2, 1>();
+            (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((k_sssp_wave<2, 1>), g, dim3(64), lb, s, *b);
         } else {
-            const size_t lb = wv_lds_bytes<4>();
-            (void)hipFuncSetAttribute((const void *)k_sssp_wave<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            hipLaunchKernelGGL(k_sssp_wave<4>, g, dim3(64), lb, s, *b);
+            const size_t lb = wv_lds_bytes<4, 1>();
+            (void)hipFuncSetAttribute((const void *)k_sssp_wave<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((k_sssp_wave<4, 1>), g, dim3(64), lb, s, *b);
         }
         return;
     }
