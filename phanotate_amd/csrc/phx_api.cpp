@@ -936,12 +936,16 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         auto early_k = [&](int k) { return ((mask >> (4 * k + 2)) & 1) && ((mask >> (4 * k + 1)) & 1) && (((mask >> (16 + k)) | (mask >> (20 + k))) & 1); }; // such contigs existed in the run this one is modelled on
         for (int k = 0; k < 4; k++) early = early || early_k(k);
         early = early && c->aux[2];
-        if ((nclass > 1 || early) && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
-        if (early) {
+        // the wavefront kernel's roomy configuration takes other contigs than the tight one (k_wave_plan decided): beside it, on the side stream
+        const bool roomy_side = ((mask >> 3) & 1) && c->aux[2] && !c->one_stream;
+        if ((nclass > 1 || early || roomy_side) && c->aux[0]) HIPCHK(c, hipEventRecord(c->ev_fork, s)); // fork point: before any of the launches
+        if (early || roomy_side) {
             HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork, 0));
             used[2] = true;
-            for (int k = 3; k >= 0; k--)
-                if (early_k(k)) phxk_sssp(&b, nl_of[k], 1, (size_t)lds[k], c->aux[2]);
+            if (roomy_side) phxk_sssp(&b, 2, 3, 0, c->aux[2]);
+            if (early)
+                for (int k = 3; k >= 0; k--)
+                    if (early_k(k)) phxk_sssp(&b, nl_of[k], 1, (size_t)lds[k], c->aux[2]);
             HIPCHK(c, hipEventRecord(c->ev_join[2], c->aux[2]));
         }
         for (int k = 3; k >= 0; k--) { // widest integers first: fewest contigs, longest per-contig time
@@ -953,15 +957,15 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
                 st = c->aux[a];
             }
             for (int mode = 3; mode >= 0; mode--) // 3: the wavefront kernel's roomy configuration (few contigs, if any), 2: its tight one
-                if ((mask >> (4 * k + mode)) & 1) {
-                    if (early && mode == 1 && early_k(k)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launch: it skips what that one solved
+                if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side)) {
+                    if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                 }
             nlaunch++;
         }
         for (int a = 0; a < 2; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
-        if (early) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
+        if (early || roomy_side) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
     }
     {
         StageTimer t(c, ST_INORDER);
