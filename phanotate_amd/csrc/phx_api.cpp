@@ -169,7 +169,7 @@ struct phx_ctx {
     int graph_flags = -1;
     void *h_stage = nullptr; // pinned staging for H2D of ASCII
     size_t h_stage_cap = 0;
-    std::vector<DGene> h_genes;
+    DGene *h_genes = nullptr; size_t h_genes_cap = 0; // pinned staging of the gene records (D2H at link rate)
     // profiling
     bool prof = false;
     uint32_t prof_mask = 0xffffffffu; // stages that are bracketed by events when prof is on
@@ -628,6 +628,7 @@ void phx_destroy(phx_ctx *c) {
     if (c->d_t4) (void)hipFree(c->d_t4);
     if (c->d_t3) (void)hipFree(c->d_t3);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_genes) (void)hipHostFree(c->h_genes);
     c->meta.release();
     if (c->res) (void)hipHostFree(c->res);
     c->res = nullptr; c->res_cap = 0;
@@ -1182,6 +1183,16 @@ int phx_run(phx_ctx *c) {
     return PHX_OK;
 }
 
+static int ensure_gene_stage(phx_ctx *c, size_t n) {
+    if (n <= c->h_genes_cap) return PHX_OK;
+    if (c->h_genes) HIPCHK(c, hipHostFree(c->h_genes));
+    c->h_genes = nullptr; c->h_genes_cap = 0;
+    const size_t cap = n + n / 4 + 1024;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_genes, cap * sizeof(DGene), hipHostMallocDefault));
+    c->h_genes_cap = cap;
+    return PHX_OK;
+}
+
 int phx_download(phx_ctx *c, phx_result *out) {
     if (!c || (!out && c->n > 0)) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
@@ -1189,9 +1200,9 @@ int phx_download(phx_ctx *c, phx_result *out) {
     HIPCHK(c, hipSetDevice(c->device));
     int64_t total = 0;
     for (int i = 0; i < c->n; i++) total = std::max<int64_t>(total, c->res[i].gene_off + c->res[i].n_genes);
-    c->h_genes.resize((size_t)total);
+    { const int rg = ensure_gene_stage(c, (size_t)total); if (rg) return rg; }
     if (total) {
-        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_genes, (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < c->n; i++) {
@@ -1228,9 +1239,9 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
         return PHX_OK;
     }
     if (cap < total) return PHX_E_ARG;
-    c->h_genes.resize((size_t)hi);
+    { const int rg = ensure_gene_stage(c, (size_t)hi); if (rg) return rg; }
     if (hi) {
-        HIPCHK(c, hipMemcpyAsync(c->h_genes.data(), (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)hi, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_genes, (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)hi, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     static_assert(sizeof(DGene) == sizeof(phx_gene), "device and ABI gene records have the same layout");
