@@ -204,6 +204,7 @@ def main():
                     help="N > 1 ranks on ONE GPU: the sharded code path (partition, per-rank shards, gather of the flat arrays over the group's gloo half) where no multi-GPU node is at hand; only the barrier / reductions differ from a multi-GPU launch (gloo instead of RCCL); its numbers mean nothing")
     ap.add_argument("--force-dist", action="store_true", help="bring the process group up even with one rank (exercises the RCCL + gloo group of a multi-GPU launch on a 1-GPU box)")
     ap.add_argument("--dump-merged", default=None, help="rank 0 writes the merged (status, offsets, genes) of the host-to-host region to this .npz (tests)")
+    ap.add_argument("--no-pipeline-host", action="store_true", help="skip the host-to-host region of two_batches_in_flight (a kernel trace then ends with the resident steps of the two contexts)")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic (use profiles/traffic.json)")
     args = ap.parse_args()
 
@@ -355,7 +356,7 @@ def main():
             a2.wait()
         barrier()
         dt_pipe = max_over_ranks(time.perf_counter() - t0)
-    if world == 1 and not args.no_pipeline:
+    if world == 1 and not args.no_pipeline and not args.no_pipeline_host:
         for _ in pipe.run([seqs, seqs]):
             pass
         barrier()
@@ -398,7 +399,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak" if world == 1 and n_total != 10000 else "strong",
             "vs_baseline": None,
-            "dtype": "u8/int128 (fp64 edge weights)",
+            "dtype": "u8 bases / fp64 scores / int64 edge weights / int128 distances",
             "data": ("synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)") + (" [SMOKE: all ranks on one GPU, gloo]" if args.smoke_single_device else ""),
             "value_is": "inputs resident in HBM when the timed region starts (task contract); host ASCII -> host gene lists is `host_to_host`",
             "config": {

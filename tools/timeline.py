@@ -10,8 +10,12 @@ with open(sys.argv[1]) as f:
 rows.sort()
 # a step begins at k_features
 starts = [i for i, r in enumerate(rows) if "k_features" in r[2]]
-sel = starts[-2] if len(starts) > 1 else 0
-step = rows[sel:starts[-1]] if len(starts) > 1 else rows
+# which step: argv[2] = index of the step's k_features launch (default: the last complete step of the trace)
+if len(sys.argv) > 2 and len(starts) > int(sys.argv[2]) + 1:
+    k = int(sys.argv[2]); step = rows[starts[k]:starts[k + 1]]
+else:
+    sel = starts[-2] if len(starts) > 1 else 0
+    step = rows[sel:starts[-1]] if len(starts) > 1 else rows
 t0 = step[0][0]; last_end = t0; idle = 0
 for s, e, n in step:
     gap = s - last_end
