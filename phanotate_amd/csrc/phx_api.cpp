@@ -130,6 +130,12 @@ struct phx_ctx {
     const void *attached = nullptr;
     bool packed = false;     // b_ascii holds nibbles (phx_upload), not letters (phx_attach)
     hipEvent_t ev_upload = nullptr; bool upload_pending = false; // recorded behind the last copy of phx_upload
+    hipEvent_t ev_layout = nullptr; bool layout_pending = false; // recorded behind push_layout's copies
+    hipEvent_t ev_piece[2] = {nullptr, nullptr};                  // phx_upload: a piece's copy -> its k_features launch
+    void *h_tiles = nullptr; size_t h_tiles_cap = 0;             // pinned copy of the tile table
+    bool eager_now = false;    // ... and this launch is that run (launch_once)
+    bool eager_done = false;   // phx_upload has already reset the accumulators and run k_features for this batch: the next run starts behind them
+    bool trna_clean = true;    // no phx_set_trnas with hits since the layout was set
     std::unique_ptr<StagePool> pool;
     // buffers
     DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_owi, b_oflag, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
@@ -404,6 +410,8 @@ int fetch_meta(phx_ctx *c) {
 }
 
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
+    if (c->layout_pending) { HIPCHK(c, hipEventSynchronize(c->ev_layout)); c->layout_pending = false; } // push_layout's copies read the records rewritten below
+    c->eager_done = false; c->trna_clean = true;
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     c->meta_stale = false;
     c->has_trna = false; c->h_tnode.clear();
@@ -564,7 +572,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
         else if (hipStreamCreateWithFlags(&c->aux[a], hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return fail(PHX_E_HIP); }
         if (hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     }
-    if (hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_layout, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_piece[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_piece[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
@@ -636,6 +645,9 @@ void phx_destroy(phx_ctx *c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     for (int a = 0; a < 4; a++) { if (c->aux[a] && !c->one_stream) (void)hipStreamDestroy(c->aux[a]); if (c->ev_join[a]) (void)hipEventDestroy(c->ev_join[a]); }
     if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+    if (c->ev_layout) (void)hipEventDestroy(c->ev_layout);
+    for (int k = 0; k < 2; k++) if (c->ev_piece[k]) (void)hipEventDestroy(c->ev_piece[k]);
+    if (c->h_tiles) (void)hipHostFree(c->h_tiles);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_fork_plan) (void)hipEventDestroy(c->ev_fork_plan);
     if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
@@ -645,6 +657,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+namespace { int push_layout(phx_ctx *c); }
 
 int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len) {
     if (!c || n < 0 || (n > 0 && (!seq || !len))) return PHX_E_ARG;
@@ -670,6 +684,28 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     // them on the earliest unfinished piece (items of <= 128 Kbases, taken in order), so that the first copy starts after 1/threads
     // of a piece's packing time; the calling thread enqueues each piece as soon as its last item is done.
     StageTimer t(c, ST_COPY);
+    // k_features needs nothing but the bases: it is launched piece by piece behind the copies, on a side stream, so that the link and
+    // the kernel work side by side and the run that follows starts at the ORF scan.  (The accumulators it adds to are reset here, as
+    // the head of a run does; a run that is repeated on this batch — or retried with other buffer sizes — does all of it again.)
+    bool eager = c->n > 0 && !c->tiles.empty() && c->aux[1] && !c->one_stream && !c->prof;
+    std::vector<int> tile_first;
+    DBatch fb;
+    if (eager) {
+        if ((rc = ensure_position_buffers(c))) return rc;
+        if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
+        if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
+        if ((rc = push_layout(c))) return rc;
+        hipStream_t s0 = c->stream;
+        HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s0));
+        HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s0));
+        HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s0));
+        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)c->n, hipMemcpyDeviceToDevice, s0));
+        fill_batch(c, &fb);
+        tile_first.assign((size_t)n + 1, (int)c->tiles.size());
+        for (int k = (int)c->tiles.size() - 1; k >= 0; k--) tile_first[(size_t)c->tiles[(size_t)k].contig] = k; // tiles are in contig order
+        for (int i = n - 1; i >= 0; i--) if (tile_first[(size_t)i] > tile_first[(size_t)i + 1]) tile_first[(size_t)i] = tile_first[(size_t)i + 1]; // (a contig without tiles)
+    }
+    int n_sent = 0;
     struct Piece { int i0, i1; int64_t beg, end; int items; };
     struct Item { const char *in; int64_t n; uint8_t *out; int piece; };
     std::vector<Piece> pieces;
@@ -690,7 +726,15 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     }
     auto send_piece = [&](const Piece &pc) { // [beg, end) in bases -> bytes (piece boundaries are row starts: even)
         const size_t b0 = (size_t)(pc.beg >> 1), b1 = (size_t)((pc.end + 1) >> 1);
-        return hipMemcpyAsync((char *)c->b_ascii.p + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync((char *)c->b_ascii.p + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && eager) { // this piece's tiles, as soon as its bases have landed
+            hipEvent_t ev = c->ev_piece[n_sent & 1];
+            const int t0 = tile_first[(size_t)pc.i0], t1 = tile_first[(size_t)pc.i1];
+            if ((e = hipEventRecord(ev, c->stream)) == hipSuccess && (e = hipStreamWaitEvent(c->aux[1], ev, 0)) == hipSuccess && t1 > t0)
+                phxk_features(&fb, (const DTile *)c->b_tiles.p + t0, t1 - t0, c->aux[1]);
+        }
+        n_sent++;
+        return e;
     };
     const int np = (int)pieces.size(), ni = (int)items.size();
     int nthreads = 0;
@@ -727,6 +771,12 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         c->pool->finish(); // (the workers hold references to this frame)
         HIPCHK(c, err);
     }
+    if (eager) { // the run follows the last k_features launch
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev_piece[0], c->aux[1]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_piece[0], 0));
+        c->eager_done = true;
+    }
     // No wait here: the letters are staged (the caller's strings are free again), the copies are ordered before the run on the
     // context's stream, and the next phx_upload waits for this event before it touches the staging memory.
     HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
@@ -740,6 +790,8 @@ int phx_set_trnas(phx_ctx *c, const int64_t *offsets, const int32_t *start, cons
     if (!c->uploaded) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->in_flight) (void)settle(c);
+    if (!offsets && c->trna_clean) return PHX_OK; // no hits before, none now: the batch is as phx_upload left it
+    c->trna_clean = false; c->eager_done = false; // (the records change: the run resets the accumulators and runs k_features itself)
     c->ran = false; c->graph_valid = false; c->meta0_dirty = true; c->runs_on_layout = 0;
     c->has_trna = false; c->h_tnode.clear();
     for (DMeta &m : c->meta) { m.n_tnode = 0; m.n_tedge = 0; m.tn_off = 0; m.te_off = 0; if (m.status == PHX_S_PARALLEL || m.status == PHX_S_BADTRNA) m.status = 0; }
@@ -833,19 +885,20 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     const int n = c->n;
     hipStream_t s = c->stream;
     DBatch b;
+    const bool head_done = c->eager_now; // phx_upload reset the accumulators and ran k_features behind its copies
     {
         StageTimer t(c, ST_MEMSET);
-        HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
+        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
         if (c->has_trna) HIPCHK(c, hipMemsetAsync(c->b_tbits.p, 0, (size_t)(c->tot_nbits / 3 * 4 + 8) * 8, s));
-        HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
-        HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
+        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
+        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
     }
-    {
+    if (!head_done) {
         StageTimer t(c, ST_COPY);
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToDevice, s)); // accumulators back to zero
     }
     fill_batch(c, &b);
-    { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
+    if (!head_done) { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
     // word-prefix popcounts of the bitmaps (for k_orf_stats) on a side stream, beside the ORF scan
     HIPCHK(c, hipEventRecord(c->ev_fork_pre, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_pre, 0));
@@ -991,21 +1044,11 @@ void drop_graph(phx_ctx *c) {
     c->graph_exec = nullptr; c->graph = nullptr; c->graph_valid = false;
 }
 
-// One pass over the whole path.  `learn`: read the device-side totals back after each layout kernel and size the buffers
-// from them (two extra host round trips: first run of a context, or a batch that outgrew it).  Otherwise everything is
-// enqueued at once against the buffers the context already has — as one HIP graph launch when the previous run's graph
-// still applies (same batch layout, buffers, solver classes) —; the layout kernels flag a batch that does not fit,
-// later kernels then do nothing, and the caller runs again with `learn`.
-int launch_once(phx_ctx *c, bool learn) {
-    int rc;
-    c->tapw_valid = false; c->cert_done = false;
+// The batch layout on the device, once per layout: the records a run starts from (b_meta0: offsets and lengths set, accumulators
+// zero) and the tile table of k_features.  Asynchronous, from pinned memory; ev_layout guards the host copies.
+int push_layout(phx_ctx *c) {
     hipStream_t s = c->stream;
-    if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
-    if ((rc = ensure_position_buffers(c))) return rc;
-    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
-    if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
-    if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
-    if ((rc = ensure(c, c->b_tie, (size_t)std::max<int64_t>(1 << 20, c->tie_seen + c->tie_seen / 4)))) return rc;
+    bool pushed = false;
     if (c->meta0_dirty) { // once per batch layout: the records a run starts from (offsets and lengths set, accumulators zero)
         for (DMeta &m : c->meta) {
             DMeta k = m;
@@ -1015,22 +1058,49 @@ int launch_once(phx_ctx *c, bool learn) {
             m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
             if ((k.status == PHX_S_PARALLEL || k.status == PHX_S_BADTRNA) && k.n_tedge < 0) { m.status = k.status; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74); a hit outside the contig
         }
-        HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        c->meta0_dirty = false;
+        HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s)); // (pinned: set_batch_layout waits for ev_layout before it rewrites the records)
+        c->meta0_dirty = false; pushed = true;
     }
     if (c->tiles_dirty) { // once per batch layout
-        HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->tiles.data(), sizeof(DTile) * c->tiles.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s)); // c->tiles is pageable host memory
-        c->tiles_dirty = false;
+        const size_t tb = sizeof(DTile) * c->tiles.size();
+        if (c->h_tiles_cap < tb) {
+            if (c->h_tiles) HIPCHK(c, hipHostFree(c->h_tiles));
+            c->h_tiles = nullptr; c->h_tiles_cap = 0;
+            HIPCHK(c, hipHostMalloc(&c->h_tiles, tb + tb / 4 + 4096, hipHostMallocDefault));
+            c->h_tiles_cap = tb + tb / 4 + 4096;
+        }
+        if (tb) { memcpy(c->h_tiles, c->tiles.data(), tb); HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->h_tiles, tb, hipMemcpyHostToDevice, s)); }
+        c->tiles_dirty = false; pushed = true;
     }
+    if (pushed) { HIPCHK(c, hipEventRecord(c->ev_layout, s)); c->layout_pending = true; }
+    return PHX_OK;
+}
+
+// One pass over the whole path.  `learn`: read the device-side totals back after each layout kernel and size the buffers
+// from them (two extra host round trips: first run of a context, or a batch that outgrew it).  Otherwise everything is
+// enqueued at once against the buffers the context already has — as one HIP graph launch when the previous run's graph
+// still applies (same batch layout, buffers, solver classes) —; the layout kernels flag a batch that does not fit,
+// later kernels then do nothing, and the caller runs again with `learn`.
+int launch_once(phx_ctx *c, bool learn) {
+    int rc;
+    c->tapw_valid = false; c->cert_done = false;
+    hipStream_t s = c->stream;
+    c->eager_now = c->eager_done && !c->meta0_dirty && !c->tiles_dirty; // the first launch after such an upload only: a repeated or retried run does everything
+    c->eager_done = false;
+    if (learn) c->graph_valid = false; // sizes, strides or solver classes are being re-derived
+    if ((rc = ensure_position_buffers(c))) return rc;
+    if ((rc = ensure(c, c->b_tot, sizeof(DTotals)))) return rc;
+    if (!c->h_tot) HIPCHK(c, hipHostMalloc((void **)&c->h_tot, sizeof(DTotals), hipHostMallocDefault));
+    if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tie, (size_t)std::max<int64_t>(1 << 20, c->tie_seen + c->tie_seen / 4)))) return rc;
+    if ((rc = push_layout(c))) return rc;
     int mask = 0;
     int64_t lds[4] = {0, 0, 0, 0};
     DCaps caps_now;
     current_caps(c, &caps_now);
     // capturing and instantiating a graph costs about 0.7 ms: it pays when the same batch layout is run again, not for a
     // batch that is uploaded, run once and replaced (phx_annotate on fresh contigs)
-    const bool use_graph = !learn && !c->prof && c->graphs_enabled && (c->runs_on_layout >= 2 || c->graph_valid);
+    const bool use_graph = !learn && !c->prof && !c->eager_now && c->graphs_enabled && (c->runs_on_layout >= 2 || c->graph_valid);
     bool launched = false;
     if (use_graph) {
         if (c->graph_valid && c->graph_exec && c->graph_flags == caps_now.flags) {
