@@ -658,6 +658,9 @@ void phx_destroy(phx_ctx *c) {
     delete c;
 }
 
+#ifndef PHX_UPLOAD_PIECE
+#define PHX_UPLOAD_PIECE (4 << 20)
+#endif
 namespace { int push_layout(phx_ctx *c); }
 
 int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len) {
@@ -711,7 +714,7 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     std::vector<Piece> pieces;
     std::vector<Item> items;
     {
-        const int64_t piece = 4 << 20, chunk = 128 << 10;
+        const int64_t piece = PHX_UPLOAD_PIECE, chunk = 128 << 10;
         int64_t sent = 0; int first = 0;
         for (int i = 0; i < n; i++) {
             const int64_t end = i + 1 < n ? c->meta[(size_t)i + 1].off : c->totalL; // rows are 16-base aligned: the gap belongs to the piece
