@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files per kernel (last dispatch of each kernel).
+"""Summarise rocprofv3 --pmc counter_collection.csv files per kernel: the longest dispatch of each kernel (the full-batch launch —
+phx_upload also launches k_features piece by piece; among equals the last).
 
 With --json FILE also writes {kernel: {counter: value, ...}} plus derived `hbm_bytes` per launch:
 FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
@@ -17,13 +18,19 @@ allk = collections.OrderedDict()
 for path in args:
     rows = list(csv.DictReader(open(path)))
     d = collections.OrderedDict()
+    best = {}
     for r in rows:
         k = r["Kernel_Name"]
         if "rocclr" in k:
             continue
-        e = d.setdefault(k, {})
-        e[r["Counter_Name"]] = float(r["Counter_Value"])
-        e["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        did = r.get("Dispatch_Id")
+        if k not in best or dur >= best[k][0] or did == best[k][1]:
+            if k not in best or did != best[k][1]:
+                d[k] = {}
+            best[k] = (max(dur, best[k][0]) if k in best and did == best[k][1] else dur, did)
+            d[k][r["Counter_Name"]] = float(r["Counter_Value"])
+            d[k]["dur_us"] = dur
     print(path)
     for k, v in d.items():
         dur = v.pop("dur_us")
