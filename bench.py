@@ -498,7 +498,7 @@ def main():
                 n_again = int((np.asarray(a5.certified()) == 0).sum())
                 out["strong_scaling_base"] = {"contigs": 10000, "n_gpus": 1, "value": round(len(big) * L_ / t5 / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5 * 1e3, 3),
                                               "host_to_host": {"value": round(len(big) * L_ / t5h / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5h * 1e3, 3), "contigs_solved_again_on_host": n_again,
-                                                               "what": "upload + run + download + certificate; a contig the certificate does not cover is solved again on the host in the reference's Decimal-derived integers (python, ~0.5 s per 50 kb contig), which is most of this figure when there is one"},
+                                                               "what": "upload + run + download + certificate; a contig the certificate does not cover is solved again on the host in the reference's Decimal-derived integers (python, ~0.1 s per 50 kb contig), which is most of this figure when there is one"},
                                               "genes_called_total": int(len(g5)), "contigs_with_error_status": int((st5 < 0).sum()),
                                               "what": "config 5's 10 000 contigs as one batch resident on one GPU (3 timed runs; = `bench.py --gpus 1 --contigs 10000`): divide the N > 1 lines' value by this for strong-scaling efficiency"}
                 a5.close()

@@ -204,9 +204,10 @@ class Annotator:
         status, offs, genes = result
         parts = {}
         for i in todo:
-            nd, ed, wdec = decimal_weights(self, i, seq_of(i), start_codons)
+            nd, ed, wdec = decimal_weights(self, i, seq_of(i), start_codons, flagged_only=True)
             V = len(nd)
-            E = [(int(ed[k]["src"]), int(ed[k]["dst"]), int(wdec[k] * 1000), k) for k in edge_order(nd, ed)]
+            esrc, edst = ed["src"].tolist(), ed["dst"].tolist()
+            E = [(esrc[k], edst[k], int(wdec[k] * 1000), k) for k in edge_order(nd, ed)]
             dist, par = [None] * V, [-1] * V
             dist[V - 2] = 0
             for _ in range(V + 1):
@@ -221,7 +222,7 @@ class Annotator:
             if dist[V - 1] is not None:
                 pe, v = [], V - 1
                 while v != V - 2:
-                    pe.append(par[v]); v = int(ed[par[v]]["src"])
+                    pe.append(par[v]); v = esrc[par[v]]
                 pe.reverse()  # edges source -> target; shortest_path[1:] pairwise = every second edge (phanotate.py:65-76)
                 picks = pe[1::2]
                 g = np.zeros(len(picks), _lib.GENE_DT)

@@ -42,8 +42,20 @@ def _gap(length, diff, pgap):  # functions.py:36-46
     return score + 1 / Decimal("0.05") if diff else score
 
 
+class _Lazy:
+    """A list whose entries are computed when they are first read."""
+
+    def __init__(self, n, f):
+        self.v, self.f = [None] * n, f
+
+    def __getitem__(self, k):
+        if self.v[k] is None:
+            self.v[k] = self.f(k)
+        return self.v[k]
+
+
 def orf_weights(seq, orf, gcc, gl, weights, start_names):
-    """Decimal pstop and weight of every ORF of the tap `orf` (reference order)."""
+    """Decimal pstop and weight of every ORF of the tap `orf` (reference order), each computed when it is first asked for."""
     dna = seq.lower()
     comp = {"a": "t", "t": "a", "g": "c", "c": "g"}
     # functions.py:281-284
@@ -55,8 +67,8 @@ def orf_weights(seq, orf, gcc, gl, weights, start_names):
     pos_min = [x / y for x in pos_min]
     fwd_cls = (gcc & 15).tolist()
     rev_cls = (gcc >> 4).tolist()
-    pstops, out = [], []
-    for r in orf:
+    def pstop_of(k):
+        r = orf[k]
         start, stop, frame = int(r["start"]), int(r["stop"]), int(r["frame"])
         # Orf.p_stop on the coding strand (orfs.py:162-173); letters outside acgt only count in the length
         s = dna[start - 1 : stop + 2] if frame > 0 else dna[stop - 1 : start + 2]
@@ -65,8 +77,14 @@ def orf_weights(seq, orf, gcc, gl, weights, start_names):
             na, nt, ng = nt, na, s.count("c")
         length = Decimal(len(s))
         Pa, Pt, Pg = na / length, nt / length, ng / length
-        pstop = Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg
-        pstops.append(pstop)
+        return Pt * Pa * Pa + Pt * Pg * Pa + Pt * Pa * Pg
+
+    pstops = _Lazy(len(orf), pstop_of)
+
+    def weight_of(k):
+        r = orf[k]
+        start, stop, frame = int(r["start"]), int(r["stop"]), int(r["frame"])
+        pstop = pstops[k]
         # functions.py:286-298: hold *= ((1-pstop)**pos_max[imax])**pos_min[imin] per sense codon; the factor only depends on
         # the codon's class, the running product is rounded after every multiplication as in the reference
         fac = {}
@@ -83,33 +101,32 @@ def orf_weights(seq, orf, gcc, gl, weights, start_names):
             hold = hold * f
         # Orf.score, orfs.py:122-127
         w = 1 / hold
-        k = int(r["startidx"])
-        if k >= 0:
-            w = w * weights[start_names[k]]
+        si = int(r["startidx"])
+        if si >= 0:
+            w = w * weights[start_names[si]]
         b = int(r["rbs"])
         w = w * Decimal(str(gl.training_rbs[b] / gl.background_rbs[b]))
-        out.append(-w)
-    return pstops, out
+        return -w
+
+    return pstops, _Lazy(len(orf), weight_of)
 
 
 def edge_order(nd, ed):
     """Indices of the tapped edges `ed` in Graph.iteredges order (graphs.py:121-126): by insertion rank of the source node, then
     in the order get_graph adds a node's out-edges: its ORF edge(s) (functions.py:311-318), bridges (334-354), the tRNA edge
     (509), the connect loop (360-438: right node outer, left node inner), source / target edges (440-452)."""
-    ref = nd["refidx"]
+    ref, typ, frm, pos = nd["refidx"].tolist(), nd["type"].tolist(), nd["frame"].tolist(), nd["pos"].tolist()  # (lists: structured scalars are slow)
     keys = []
-    for k, e in enumerate(ed):
-        s, d = int(e["src"]), int(e["dst"])
-        ts, td = int(nd[s]["type"]), int(nd[d]["type"])
-        fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
+    for k, (s, d) in enumerate(zip(ed["src"].tolist(), ed["dst"].tolist())):
+        ts, td, fs, fd = typ[s], typ[d], frm[s], frm[d]
         if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
-            cls = (1.5 if abs(fs) == 4 else 0, int(ref[d]), 0)
+            cls = (1.5 if abs(fs) == 4 else 0, ref[d], 0)
         elif ts == 2 or td == 3:
-            cls = (3, int(ref[d]), 0)
+            cls = (3, ref[d], 0)
         else:
-            l, r = (s, d) if nd[s]["pos"] < nd[d]["pos"] else (d, s)
-            cls = (1 if abs(int(nd[s]["pos"]) - int(nd[d]["pos"])) >= 500 else 2, int(ref[r]), int(ref[l]))
-        keys.append((int(ref[s]), cls, k))
+            l, r = (s, d) if pos[s] < pos[d] else (d, s)
+            cls = (1 if abs(pos[s] - pos[d]) >= 500 else 2, ref[r], ref[l])
+        keys.append((ref[s], cls, k))
     keys.sort()
     return [k for _, _, k in keys]
 
@@ -127,8 +144,10 @@ def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     return ["%s\t%s\t%s" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), str(weight[k] * 1000)) for k in edge_order(nd, ed)]
 
 
-def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
-    """(node tap, edge tap, the reference's Decimal weight of every tapped edge, in tap order) of contig i."""
+def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05", flagged_only=False):
+    """(node tap, edge tap, the reference's Decimal weight of every tapped edge, in tap order) of contig i.  flagged_only: Decimal
+    arithmetic only for the edges the device marked "inexact"; for every other edge trunc(Decimal(w) * 1000) equals the device's
+    integer (that is what the flag says, phx_kernels.hip: cert_eps_is_zero_fast), and the entry is that integer / 1000."""
     if isinstance(seq, (bytes, bytearray)):
         seq = seq.decode()
     gl = ann.globals(i)
@@ -157,12 +176,25 @@ def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
             return pgap  # (the reference raises here; libphx reports such a contig through its status)
         return pgap
 
+    import math
+
+    gap_memo = {}
+
+    def _gap_m(length, diff):
+        key = (length, diff)
+        if key not in gap_memo:
+            gap_memo[key] = _gap(length, diff, pgap)
+        return gap_memo[key]
+
     weight = []
-    for e in ed:
-        s, d = int(e["src"]), int(e["dst"])
-        ts, td = int(nd[s]["type"]), int(nd[d]["type"])
-        fs, fd = int(nd[s]["frame"]), int(nd[d]["frame"])
-        ps, pd = int(nd[s]["pos"]), int(nd[d]["pos"])
+    typ, frm, pos = nd["type"].tolist(), nd["frame"].tolist(), nd["pos"].tolist()
+    for s, d, wf, ix in zip(ed["src"].tolist(), ed["dst"].tolist(), ed["w"].tolist(), ed["inexact"].tolist()):
+        if flagged_only and not ix:
+            weight.append(Decimal(math.trunc(wf * 1000.0)) / 1000)
+            continue
+        ts, td = typ[s], typ[d]
+        fs, fd = frm[s], frm[d]
+        ps, pd = pos[s], pos[d]
         if ts < 2 and td < 2 and fs == fd and abs(fs) == 4 and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
             w = -Decimal(20)  # the tRNA edge, functions.py:509
         elif ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
@@ -170,13 +202,13 @@ def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
             start, stop = (ps, pd) if fs > 0 else (pd, ps)
             w = oweight[by_stop[stop][start]]
         elif ts == 2:  # functions.py:445-448
-            w = _gap(pd, False, pgap)
+            w = _gap_m(pd, False)
         elif td == 3:  # functions.py:449-452
-            w = _gap(L - ps, False, pgap)
+            w = _gap_m(L - ps, False)
         else:
             diff = fs * fd < 0 and abs(fs) != 4 and abs(fd) != 4  # a pair with a tRNA node is scored 'same' on both strand combinations (functions.py:388-399)
             if ps < pd:  # left -> right: a gap edge of the connect loop, or a bridge over a non-coding run (same formula)
-                w = _gap(pd - ps - 3, diff, pgap)
+                w = _gap_m(pd - ps - 3, diff)
             else:  # right -> left: overlap edge, pstop = ave([o1, o2]) (functions.py:385)
                 pst = Decimal((o_term(pd) + o_term(ps)) / 2)
                 w = _overlap(ps - pd + 3, diff, pst)
