@@ -42,9 +42,9 @@ def algorithmic_bytes(sz):
     return sz["L"] / 4.0 + 4.0 * sz["L"] + 64.0 * sz["n_orf"] + 32.0 * sz["n_edge"] + 64.0 * sz["n_node"]
 
 
-STAGE_KERNEL = {"sssp": "k_sssp_wave<2>", "features": "k_features", "edges_fill": "k_edges<true>", "edges_count": "k_edges<false>",
-                "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true>", "orf_count": "k_orf<false>", "nodes": "k_node_build", "score": "k_score",
-                "inorder": "k_inorder<2>"}
+STAGE_KERNEL = {"sssp": "k_sssp_wave<2, 0>", "features": "k_features", "edges_fill": "k_edges<true, false>", "edges_count": "k_edges<false, false>",
+                "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true,", "orf_count": "k_orf<false,", "nodes": "k_node_build", "score": "k_score",
+                "inorder": "k_inorder<2,"}  # substrings of the kernel names as rocprofv3 prints them
 
 
 def pmc_traffic_committed(stage, contigs, length):

@@ -9,7 +9,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-28:]))
 rows.sort()
 # a step begins at k_features
-starts = [i for i, r in enumerate(rows) if "k_features" in r[2]]
+starts = [i for i, r in enumerate(rows) if "k_features" in r[2] and r[1] - r[0] > 200000]  # (whole-batch launches: phx_upload also launches the kernel piece by piece)
 # which step: argv[2] = index of the step's k_features launch (default: the last complete step of the trace)
 if len(sys.argv) > 2 and len(starts) > int(sys.argv[2]) + 1:
     k = int(sys.argv[2]); step = rows[starts[k]:starts[k + 1]]

@@ -10,7 +10,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), q, r["Kernel_Name"].split("(")[0].replace("void ", "")[-30:]))
 rows.sort()
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-starts = [i for i, r in enumerate(rows) if "k_features" in r[3]]
+starts = [i for i, r in enumerate(rows) if "k_features" in r[3] and r[1] - r[0] > 200000]  # whole-batch launches
 sel = rows[starts[-nsteps]:]
 t0 = sel[0][0]
 qs = sorted({r[2] for r in sel})
