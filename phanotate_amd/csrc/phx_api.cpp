@@ -658,6 +658,9 @@ void phx_destroy(phx_ctx *c) {
     delete c;
 }
 
+#ifndef PHX_UPLOAD_THREADS
+#define PHX_UPLOAD_THREADS 16
+#endif
 #ifndef PHX_UPLOAD_PIECE
 #define PHX_UPLOAD_PIECE (4 << 20)
 #endif
@@ -743,7 +746,7 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     int nthreads = 0;
     if (c->totalL >= (2 << 20)) {
         const int hw = (int)std::thread::hardware_concurrency();
-        nthreads = std::min(std::max(1, ni / 4), std::max(1, std::min(16, hw / 4)));
+        nthreads = std::min(std::max(1, ni / 4), std::max(1, std::min(PHX_UPLOAD_THREADS, hw / 4)));
         if (!c->pool) c->pool.reset(new (std::nothrow) StagePool());
         if (c->pool) c->pool->grow(nthreads);
         nthreads = c->pool ? (int)c->pool->th.size() : 0; // no thread to be had: the calling thread packs everything

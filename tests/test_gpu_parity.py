@@ -1225,3 +1225,30 @@ def test_wavefront_kernel_in_both_configurations_equals_the_oracle(pa, oracle):
         check_exact_distances(ann, i)
         assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]) and np.array_equal(genes["strand"], o["gene_strand"]), i
     ann.close()
+
+
+def test_features_behind_the_upload_equal_features_inside_the_run(pa):
+    """phx_upload launches k_features piece by piece behind its copies and the first run after it starts at the ORF scan; a repeated
+    run, a run after phx_set_trnas, a profiled context (stage timers) and phx_attach do the whole path inside the run: same records."""
+    import torch
+
+    seqs = [pa.synth_contig(700 + i, 30000 + 997 * i) for i in range(12)] + [b"acgtnnacgtryk" * 40, b"acg", b"acgtxacgt" * 30]
+    a = pa.Annotator()
+    first = a.annotate_flat(seqs)            # features behind the upload
+    a.run(); again = a.download_flat()       # the whole path inside the run
+    a.upload(seqs); a.set_trnas([[] for _ in seqs]); a.run(); with_trna_call = a.download_flat()
+    a.upload(seqs); a.set_trnas(None); a.run(); no_finder = a.download_flat()
+    b = pa.Annotator(); b.set_profiling(True)
+    prof = b.annotate_flat(seqs)
+    cat = b"".join(seqs)
+    t = torch.frombuffer(bytearray(cat), dtype=torch.uint8).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    c = pa.Annotator(stream=torch.cuda.current_stream().cuda_stream)
+    c.attach(t.data_ptr(), offs); c._keep = (seqs,); c.run(); att = c.download_flat()
+    for other in (again, with_trna_call, no_finder, prof, att):
+        for x, y in zip(first, other):
+            assert x.tobytes() == y.tobytes()
+    assert first[0].tolist()[-3:] == [0, -3, -2]
+    for i in (0, 5, 12):  # per-position records as well (bins, bitmaps -> ORF table)
+        assert a.orfs(i).tobytes() == b.orfs(i).tobytes() == c.orfs(i).tobytes()
+    a.close(); b.close(); c.close()
