@@ -179,7 +179,10 @@ static void launch_certify(const DBatch *b, int vcap, hipStream_t s) {
 }
 extern "C" {
 void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
-    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
+#ifndef FEAT_GRID
+#define FEAT_GRID 8192 // workgroups that walk the tiles (grid-stride): 4 tiles each on the benchmark batch balance better than 16 (0.465 -> 0.45 ms), one or two per workgroup lose the prefetch (0.49)
+#endif
+    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < FEAT_GRID ? n_tiles : FEAT_GRID), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
 }
 // Workgroups per contig of the per-contig kernels: `full` for the benchmark's 50 kb contigs, fewer for batches of short contigs
 // (a 2 kb contig has ~100 nodes: four workgroups of 256 threads would leave three idle), by the batch's mean contig length.
