@@ -186,6 +186,12 @@ void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *strea
 }
 // Workgroups per contig of the per-contig kernels: `full` for the benchmark's 50 kb contigs, fewer for batches of short contigs
 // (a 2 kb contig has ~100 nodes: four workgroups of 256 threads would leave three idle), by the batch's mean contig length.
+#ifndef YS_EMIT
+#define YS_EMIT 6
+#endif
+#ifndef YS_STATS
+#define YS_STATS 8
+#endif
 static unsigned ysplit(const DBatch *b, unsigned full) {
     const unsigned y = (unsigned)((b->mean_len + 8191) / 8192);
     return y < 1u ? 1u : (y > full ? full : y);
@@ -194,9 +200,9 @@ void phxk_orf_count(const DBatch *b, void *stream) {
     if (b->mean_len < 16384) hipLaunchKernelGGL((k_orf<false, 256>), dim3(b->n_contig), dim3(256), 0, (hipStream_t)stream, *b);
     else hipLaunchKernelGGL((k_orf<false, ORF_COUNT_T>), dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b);
 }
-void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, 6)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, YS_EMIT)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_bit_prefix(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b); }
-void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, 8)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, YS_STATS)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(b->mean_len >= 8192 ? NT : 64), 0, (hipStream_t)stream, *b); }
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
