@@ -973,7 +973,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
     HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
-    phxk_wave_plan(&b, (mask >> 6) & 1, c->aux[3]); // bit 4*1+2: 256-bit contigs for the wavefront kernel
+    phxk_wave_plan(&b, ((mask >> 6) & 1) | (((mask >> 10) & 1) << 1), c->aux[3]); // bits 4*1+2, 4*2+2: 256- / 512-bit contigs for the wavefront kernel
     if (b.sord) phxk_sssp_order(&b, c->aux[3]);
     HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {

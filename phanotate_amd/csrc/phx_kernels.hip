@@ -282,13 +282,14 @@ void phxk_layout2(const DBatch *b, void *stream) {
 
 void phxk_sssp_order(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_sssp_order, dim3(1), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 
-int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4; }
+int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4 || nl == 8; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
 // (may) hold 256-bit contigs for the wavefront kernel, whose lanes keep fewer in-edges
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
     hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL((k_wave_plan<2, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b); // the contigs the tight configuration could not take
-    if (wide_too) hipLaunchKernelGGL((k_wave_plan<4, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    if (wide_too & 1) hipLaunchKernelGGL((k_wave_plan<4, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    if (wide_too & 2) hipLaunchKernelGGL((k_wave_plan<8, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
 }
 
 // mode 0: global-memory kernel (+ k_path); mode 1: workgroup-per-contig LDS kernel with `lds_bytes` of dynamic LDS;
@@ -306,10 +307,14 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
             const size_t lb = wv_lds_bytes<2, 1>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
             hipLaunchKernelGGL((k_sssp_wave<2, 1>), g, dim3(64), lb, s, *b);
-        } else {
+        } else if (nl == 4) {
             const size_t lb = wv_lds_bytes<4, 1>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
             hipLaunchKernelGGL((k_sssp_wave<4, 1>), g, dim3(64), lb, s, *b);
+        } else {
+            const size_t lb = wv_lds_bytes<8, 1>();
+            (void)hipFuncSetAttribute((const void *)k_sssp_wave<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            hipLaunchKernelGGL((k_sssp_wave<8, 1>), g, dim3(64), lb, s, *b);
         }
         return;
     }

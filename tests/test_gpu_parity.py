@@ -1252,3 +1252,27 @@ def test_features_behind_the_upload_equal_features_inside_the_run(pa):
     for i in (0, 5, 12):  # per-position records as well (bins, bitmaps -> ORF table)
         assert a.orfs(i).tobytes() == b.orfs(i).tobytes() == c.orfs(i).tobytes()
     a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("ncodons", [7500, 9500])
+def test_512_bit_contigs_on_the_wavefront_kernel(pa, oracle, ncodons):
+    """A 22-28 kb stop-free reading frame with about a hundred in-frame starts: the path sums need 512 bits.  k_sssp_wave<8> (the
+    wavefront kernel's number type is generic in its limb count; its cached in-edge weights stay 64 bits wide and the wide ones sit
+    on the LDS side list) takes such a contig as long as its stop node's in-edges fit the lanes and the spill list: distances
+    exact against python ints, genes = the exact solution of the oracle's graph."""
+    rng = np.random.RandomState(ncodons)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    quiet = [c for c in sense if c not in ("atg", "gtg", "ttg")]
+    body = ["atg" if rng.rand() < 0.01 else quiet[rng.randint(len(quiet))] for _ in range(ncodons)]
+    seq = pa.synth_contig(900, 15000).decode() + "atg" + "".join(body) + "taa" + pa.synth_contig(1900, 15000).decode()
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    gl = ann.globals(0)
+    assert status == 0
+    assert gl.n_limbs == 8 and gl.sssp_kernel == 2 and gl.sssp_handed_back == 0, (gl.n_limbs, gl.sssp_kernel, gl.sssp_handed_back)
+    o = oracle.run(seq, stages=2)
+    dist, want = _py_bellman_ford_genes(o)
+    assert [(int(g["left"]), int(g["right"])) for g in genes] == want
+    check_exact_distances(ann, 0)
+    assert ann.certified()[0] in (0, 1)
+    ann.close()
