@@ -35,7 +35,7 @@ def eps_of(w, inexact, scale=1.0):
     a = float(abs(t)) + 1.0 if abs(t) < 2 ** 62 else abs(float(t))
     ex = abs(math.frexp(a)[1])
     err = a * float(ex + 8) * (scale * 2.0 ** -46)
-    return int(math.ceil(err)) + 1
+    return int(math.floor(err)) + 1
 
 
 def flag_of(w, scale=1.0):
