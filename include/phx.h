@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-#define PHX_VERSION 300 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait;
-                         * 0.3.0: phx_certified, phx_globals.certified, PHX_S_BADTRNA, more PHX_CREATE_* flags */
+#define PHX_VERSION 400 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait;
+                         * 0.3.0: phx_certified, phx_globals.certified, PHX_S_BADTRNA, more PHX_CREATE_* flags;
+                         * 0.4.0: phx_params.start_w_text (the struct grew), phx_params_from_flags, the exact re-solve moved below the ABI
+                         *        (phx_download* deliver reference-exact genes; phx_certified reports 2), phx_dump_text, PHX_CREATE_NO_EXACT */
 #define PHX_MAX_CODONS 16
 
 /* library-level errors */
@@ -63,6 +65,11 @@ typedef struct phx_params {
     double start_w[PHX_MAX_CODONS];        /* weight / max(weight), file_handling.py:58-62 */
     int32_t n_stop;                        /* -e/--stop_codons */
     char stop[PHX_MAX_CODONS][4];
+    /* The weights as the user wrote them on -s (before the division by their maximum), e.g. "0.85", "0.10", "0.05": the reference
+     * holds Decimal(text) / max (file_handling.py:58-62), 28 digits that a double cannot carry, and the exactness guarantee of
+     * phx_download* / phx_certified is stated against THAT value.  An entry left empty means "the shortest decimal that reads back as
+     * start_w[i]" (what Decimal(repr(x)) would be).  phx_default_params and phx_params_from_flags fill both. */
+    char start_w_text[PHX_MAX_CODONS][32];
 } phx_params;
 
 /* One called gene = one ORF edge on the shortest path (phanotate.py:71-76, locus.py:29-37).
@@ -151,6 +158,10 @@ const char *phx_last_error(const phx_ctx *ctx);
 
 /* Fills *p with the reference defaults: atg:0.85,gtg:0.10,ttg:0.05 / tag,tga,taa / minlen 90. */
 void phx_default_params(phx_params *p);
+/* The same from the reference's flags (file_handling.py:51-66): start_codons "atg:0.85,gtg:0.10,ttg:0.05" (codon:weight pairs; a
+ * repeated codon keeps its first place and its last weight, like the dict the reference builds), stop_codons "tag,tga,taa", minlen.
+ * NULL strings mean the defaults.  Codons are lower-cased; PHX_E_PARAM on anything that is not 3 letters of acgt / a decimal number. */
+int phx_params_from_flags(const char *start_codons, const char *stop_codons, int32_t minlen, phx_params *p);
 
 /* device: HIP ordinal.  stream: a hipStream_t the caller owns, or NULL to let the ctx create its own (non-blocking: it
  * does NOT synchronise with HIP's null stream).  All kernels and copies of this ctx are issued on it. */
@@ -174,6 +185,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_POISON 256u    /* every device buffer the context allocates is filled with the byte 0xA5 first: the library must not depend on fresh memory being zero */
 #define PHX_CREATE_ONE_STREAM 512u /* no side streams: every kernel of a run on the context's one stream, in program order */
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
+#define PHX_CREATE_NO_EXACT 1024u /* phx_download* hand out the device's gene lists as they are: no certificate is asked for and no contig is solved again on the host */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
 
@@ -203,22 +215,33 @@ int phx_run(phx_ctx *ctx);                        /* every kernel of the path; b
  * waits for it first, so the pair is an optimisation, never a requirement.  phx_wait without a run: PHX_OK if results are there. */
 int phx_run_async(phx_ctx *ctx);
 int phx_wait(phx_ctx *ctx);
+/* Both download calls deliver gene lists that are the reference's: they ask for the certificate (phx_certified) and a contig the
+ * device could not certify is solved again on the host, inside this call, on the reference's own Decimal-derived integers
+ * (csrc/phx_exact.inc; worker threads, one contig each) — expected for none of a batch's contigs, see phx_certified.  A context
+ * created with PHX_CREATE_NO_CERTIFY or PHX_CREATE_NO_EXACT skips both and hands out the device's lists. */
 int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] */
 /* The same into caller-owned flat arrays (what a language binding wants: no per-contig allocation): genes of contig i are
  * genes[offsets[i] .. offsets[i+1]), in path order; status[i] as phx_result.status.  offsets has n+1 entries.  With
  * genes == NULL only offsets, status and total are filled (size query); cap = number of phx_gene records genes can take. */
 int phx_download_flat(phx_ctx *ctx, phx_gene *genes, int64_t cap, int64_t *offsets /* [n+1] */, int32_t *status /* [n] */, int64_t *total);
 
-/* Is every gene list proven to be what the REFERENCE'S integers give?  libphx solves on trunc(fp64(w) * 1000), the reference on
- * trunc(Decimal(w) * 1000) with 28 digits (edges.py:17-23); for |w| beyond ~1e13 the two differ in their low digits.  After the
- * solve the device proves, per contig and in exact integer arithmetic, that no such difference can change the path (an optimality
- * certificate for every weight vector inside the error bounds, csrc/phx_certify.inc).  cert[i] = 1: proven (also for contigs with
- * an error status or without a path); 0: not proven — the genes are the exact solution for the fp64-derived integers and in all
- * likelihood the reference's too, but a caller that needs the guarantee solves contig i again on the Decimal-derived integers
- * (phanotate_amd/api.py does: Annotator.resolve_uncertified); -1: the context was created with PHX_CREATE_NO_CERTIFY.
- * The proof is computed when it is first asked for after a run (here, or by phx_tap_globals), from the state the run left on the
- * device — ~0.2 ms for a thousand 50 kb contigs; phx_run itself does not pay for it. */
+/* Is every gene list what the REFERENCE'S integers give?  The reference solves on trunc(Decimal(w) * 1000) with 28 digits
+ * (edges.py:17-23); the device derives its integers in fp64 and, where fp64 cannot decide the truncation, in double-double, and
+ * flags the edges whose integer it still cannot prove equal to the reference's (the error bound of the Decimal chain
+ * itself).  After the solve it proves, per contig and in exact integer arithmetic, that no difference inside those bounds can change
+ * the path (an optimality certificate, csrc/phx_certify.inc).  cert[i] =
+ *   1: proven on the device (also for contigs with an error status or without a path);
+ *   2: not proven on the device, so the contig was solved again on the host on the reference's own integers (the Decimal chain
+ *      replayed by csrc/phx_dec.c + phx_exact.inc) and phx_download* deliver THAT result;
+ *   0: not proven and not solved again (context created with PHX_CREATE_NO_EXACT, or the replay met an operation it does not restate:
+ *      never on the reference's inputs) — the genes are the exact solution for the device's integers;
+ *  -1: the context was created with PHX_CREATE_NO_CERTIFY.
+ * The proof is computed when it is first asked for after a run (here, by phx_download*, or by phx_tap_globals), from the state the
+ * run left on the device — ~0.2 ms for a thousand 50 kb contigs; phx_run itself does not pay for it. */
 int phx_certified(phx_ctx *ctx, int8_t *cert /* [n] */);
+/* on = 0: phx_download* / phx_certified stop short of the host re-solve (as PHX_CREATE_NO_EXACT) and hand out the device's lists
+ * for every contig, also for those already solved again; on = 1 (the default) switches it back.  For tests and measurements. */
+int phx_set_exact(phx_ctx *ctx, int on);
 
 /* ---- stage taps on the batch last processed by phx_run (parity tests) ---- */
 int phx_tap_globals(phx_ctx *ctx, int32_t contig, phx_globals *out);
@@ -263,6 +286,12 @@ int phx_synth_contig(uint64_t seed, int64_t L, char *out);
 /* The 4096-entry leftward-6-mer RBS score table the position kernel uses (4 offset classes packed
  * in one uint32, class A=offsets 3-4 in bits 0-7, B=5-10, C=11-12, D=13-15); for CPU-side tests. */
 int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t *t4 /* [256] */, uint32_t *t3 /* [64] */);
+
+/* The reference's number type on the host (csrc/phx_dec.c: Python's decimal.Decimal at prec 28, ROUND_HALF_EVEN), for the tests:
+ * op = "add" "sub" "mul" "div" "pow" "ln" "exp" on the decimal texts a (and b) at `prec` digits, "str" (a as Decimal.__str__ prints
+ * it), "float" (Decimal(float(a))), "repr" (repr(float(a))), "trunc1000" (int(a * 1000) as 18 hex words), "dd" (a as a double-double).
+ * The result text goes to out; returns its length or a negative error. */
+int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *out, int cap);
 
 /* ---- host I/O of the CLI (no device needed; phx_host.c) ----
  * Files and texts beyond a few MB are parsed / formatted by worker threads (one per online core, at most 16; the environment

@@ -13,36 +13,14 @@ from ._lib import PhxError
 
 
 def make_params(start_codons="atg:0.85,gtg:0.10,ttg:0.05", stop_codons="tag,tga,taa", minlen=90):
-    """Same flag syntax and normalisation as file_handling.get_args (file_handling.py:51-66)."""
+    """Same flag syntax and normalisation as file_handling.get_args (file_handling.py:51-66): phx_params_from_flags.  The weights also
+    travel as the texts the user wrote (phx_params.start_w_text): the reference holds Decimal(text) / max."""
     p = _lib.Params()
-    p.minlen = int(minlen)
-    def codon_ok(c):
-        if len(c) != 3 or any(x not in "acgt" for x in c):
-            raise ValueError("codon %r: libphx takes codons of exactly 3 letters out of acgt" % c)
-        return c
-
-    pairs = []
-    for x in start_codons.split(","):
-        if x.count(":") != 1:
-            raise ValueError("start codon %r: expected codon:weight" % x)
-        pairs.append(tuple(x.split(":")))
-    seen = {}
-    for codon, w in pairs:  # dict semantics: a repeated codon keeps its first position, last weight
-        seen[codon_ok(codon.lower())] = float(w)
-    m = max(seen.values())
-    if len(seen) > _lib.MAXC:
-        raise ValueError("at most %d start codons" % _lib.MAXC)
-    p.n_start = len(seen)
-    for i, (codon, w) in enumerate(seen.items()):
-        p.start[i].value = codon.encode()
-        p.start_w[i] = w / m
-    stops = [codon_ok(c.lower()) for c in stop_codons.split(",")]
-    if len(stops) > _lib.MAXC:
-        raise ValueError("at most %d stop codons" % _lib.MAXC)
-    p.n_stop = len(stops)
-    for i, c in enumerate(stops):
-        p.stop[i].value = c.encode()
-    p.start_codons_text = start_codons  # the flag as given: the Decimal replay of an uncertified contig divides Decimal(weight) by the maximum itself
+    rc = _lib.lib().phx_params_from_flags(start_codons.encode(), stop_codons.encode(), int(minlen), C.byref(p))
+    if rc:
+        raise ValueError("start / stop codons %r / %r, minlen %r: libphx takes codon:weight pairs and codons of exactly 3 letters out of acgt, "
+                         "at most %d of each, minlen >= 6 (%s)" % (start_codons, stop_codons, minlen, _lib.MAXC, _lib.lib().phx_strerror(rc).decode()))
+    p.start_codons_text = start_codons  # the flag as given (dump.py's Decimal replay reads it)
     return p
 
 
@@ -62,7 +40,7 @@ class Annotator:
     0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
     context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
-    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512}  # PHX_CREATE_* development / test switches
+    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024}  # PHX_CREATE_* development / test switches
 
     def __init__(self, params=None, device=0, stream=None, flags=()):
         self.L = _lib.lib()
@@ -146,22 +124,22 @@ class Annotator:
     def wait(self):
         self._chk(self.L.phx_wait(self.h), "phx_wait")
 
-    def _seq_of(self, i):
-        keep = self._keep
-        if isinstance(keep[0], list):
-            return keep[0][i]
-        return C.string_at(int(keep[0][i]), int(keep[1][i]))  # upload_raw: addresses and lengths
-
     def download_flat(self, exact=True):
         """(status int32[n], offsets int64[n+1], genes structured array[total]): genes of contig i are genes[offsets[i]:offsets[i+1]]
-        in path order (phx_download_flat: no per-contig allocation).  exact: a contig the device could not certify against the
-        reference's Decimal-derived integers (phx_certified; none is expected) is solved again on those integers on the host
-        (resolve_uncertified; its indices are then in self.resolved)."""
+        in path order (phx_download_flat: no per-contig allocation).  The library delivers the reference's genes: a contig the device
+        could not certify against the reference's Decimal-derived integers (phx_certified; none is expected) is solved again on those
+        integers inside phx_download_flat (csrc/phx_exact.inc); its indices are then in self.resolved.  exact=False: the device's
+        own lists for every contig (phx_set_exact; tests and measurements)."""
+        if not exact:
+            self._chk(self.L.phx_set_exact(self.h, 0), "phx_set_exact")
+            try:
+                res = self._download_flat()
+            finally:
+                self._chk(self.L.phx_set_exact(self.h, 1), "phx_set_exact")
+            self.resolved = []
+            return res
         res = self._download_flat()
-        self.resolved = []
-        if exact and self.n and hasattr(self, "_keep") and len(self._keep) >= 2 and (self.certified() == 0).any():
-            st, offs, genes, self.resolved = self.resolve_uncertified(self._seq_of, res, getattr(self.params, "start_codons_text", "atg:0.85,gtg:0.10,ttg:0.05"))
-            res = (st, offs, genes)
+        self.resolved = [int(i) for i in np.nonzero(self.certified() == 2)[0]] if self.n else []
         return res
 
     def _download_flat(self):
@@ -183,62 +161,12 @@ class Annotator:
         return status[:n], offs, genes[: int(total.value)]
 
     def certified(self):
-        """int8[n]: 1 the contig's genes are proven to be what the reference's Decimal-derived integers give (phx_certified), 0 not
-        proven, -1 the context runs without the certificate."""
+        """int8[n]: 1 the contig's genes are proven on the device to be what the reference's Decimal-derived integers give
+        (phx_certified), 2 not proven there and solved again on those integers on the host (inside the library), 0 neither,
+        -1 the context runs without the certificate."""
         c = np.zeros(max(self.n, 1), np.int8)
         self._chk(self.L.phx_certified(self.h, c.ctypes.data_as(C.c_void_p)), "phx_certified")
         return c[: self.n]
-
-    def resolve_uncertified(self, seq_of, result, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
-        """The guarantee for the contigs the device could not certify (expected: none).  For each of them the reference's own integers
-        are replayed on the host — Decimal weights from the integers the GPU delivers (dump.decimal_weights: edges.py:17-23,
-        functions.py:26-46,286-301), the solver's in-place Bellman-Ford over Graph.iteredges order with a strict '<' (phanotate.py:56-64)
-        in python ints — and the contig's genes are replaced by that path's.  `seq_of(i)` returns contig i's sequence; `result` is the
-        (status, offsets, genes) of download_flat.  Returns (status, offsets, genes, indices that were solved again)."""
-        cert = self.certified()
-        todo = [int(i) for i in np.nonzero(cert == 0)[0] if result[0][i] >= 0]
-        if not todo:
-            return result[0], result[1], result[2], []
-        from .dump import decimal_weights, edge_order
-
-        status, offs, genes = result
-        parts = {}
-        for i in todo:
-            nd, ed, wdec = decimal_weights(self, i, seq_of(i), start_codons, flagged_only=True)
-            V = len(nd)
-            esrc, edst = ed["src"].tolist(), ed["dst"].tolist()
-            E = [(esrc[k], edst[k], int(wdec[k] * 1000), k) for k in edge_order(nd, ed)]
-            dist, par = [None] * V, [-1] * V
-            dist[V - 2] = 0
-            for _ in range(V + 1):
-                ch = False
-                for u, v, w, k in E:
-                    du = dist[u]
-                    if du is not None and (dist[v] is None or du + w < dist[v]):
-                        dist[v] = du + w; par[v] = k; ch = True
-                if not ch:
-                    break
-            g = np.zeros(0, _lib.GENE_DT)
-            if dist[V - 1] is not None:
-                pe, v = [], V - 1
-                while v != V - 2:
-                    pe.append(par[v]); v = esrc[par[v]]
-                pe.reverse()  # edges source -> target; shortest_path[1:] pairwise = every second edge (phanotate.py:65-76)
-                picks = pe[1::2]
-                g = np.zeros(len(picks), _lib.GENE_DT)
-                for j, k in enumerate(picks):
-                    a, b_ = int(ed[k]["src"]), int(ed[k]["dst"])
-                    g[j] = (int(nd[a]["pos"]), int(nd[b_]["pos"]) + 2, -1 if nd[a]["frame"] < 0 else 1, int(nd[a]["frame"]), float(ed[k]["w"]))
-            parts[i] = g
-        counts = np.diff(offs).copy()
-        for i, g in parts.items():
-            counts[i] = len(g)
-        new_offs = np.zeros(len(offs), np.int64)
-        np.cumsum(counts, out=new_offs[1:])
-        out = np.zeros(int(new_offs[-1]), genes.dtype)
-        for i in range(len(status)):
-            out[new_offs[i] : new_offs[i + 1]] = parts[i] if i in parts else genes[offs[i] : offs[i + 1]]
-        return status, new_offs, out, todo
 
     def download(self):
         """[(status, genes structured array)] per contig; the arrays are views into one flat buffer (phx_download_flat)."""

@@ -14,11 +14,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "phx_internal.h"
+extern "C" {
+#include "phx_dec.h"
+}
 
 namespace {
 
@@ -150,6 +154,10 @@ struct phx_ctx {
     DevBuf b_cint, b_csig; // scratch of k_certify (per node)
     bool certify = true;   // phx_certified works (PHX_CREATE_NO_CERTIFY: it reports -1 and the scratch is not allocated)
     bool cert_done = false; // k_certify has run on the results the context holds
+    bool exact = true;       // phx_download* solve uncertified contigs again on the host (PHX_CREATE_NO_EXACT: they do not)
+    bool exact_done = false; // ... and that has happened for the results the context holds
+    std::map<int, std::vector<DGene>> exact_genes; // contig -> its genes from the host re-solve (phx_exact.inc)
+    int exact_failed = 0;    // contigs whose replay met an operation phx_dec.c does not restate (left as the device solved them)
     double cert_scale = 1.0;
     bool cert_wide = false; // test switch: every contig through k_certify_wide
     bool poison = false;    // test switch: new device buffers are filled with a byte pattern
@@ -261,6 +269,8 @@ int check_params(const phx_params *p) {
         for (int j = 0; j < 3; j++) if (code_of(p->start[i][j]) < 0) return PHX_E_PARAM;
         if (p->start[i][3] != 0) return PHX_E_PARAM;
         if (!(p->start_w[i] == p->start_w[i])) return PHX_E_PARAM;
+        if (!memchr(p->start_w_text[i], 0, sizeof(p->start_w_text[i]))) return PHX_E_PARAM;
+        if (p->start_w_text[i][0]) { dec_t t; if (dec_from_str(&t, p->start_w_text[i])) return PHX_E_PARAM; }
     }
     for (int i = 0; i < p->n_stop; i++) {
         for (int j = 0; j < 3; j++) if (code_of(p->stop[i][j]) < 0) return PHX_E_PARAM;
@@ -519,8 +529,57 @@ void phx_default_params(phx_params *p) {
     strcpy(p->start[0], "atg"); strcpy(p->start[1], "gtg"); strcpy(p->start[2], "ttg");
     // file_handling.py:58-62: weights divided by their maximum
     p->start_w[0] = 0.85 / 0.85; p->start_w[1] = 0.10 / 0.85; p->start_w[2] = 0.05 / 0.85;
+    strcpy(p->start_w_text[0], "0.85"); strcpy(p->start_w_text[1], "0.10"); strcpy(p->start_w_text[2], "0.05");
     p->n_stop = 3;
     strcpy(p->stop[0], "tag"); strcpy(p->stop[1], "tga"); strcpy(p->stop[2], "taa");
+}
+
+int phx_params_from_flags(const char *start_codons, const char *stop_codons, int32_t minlen, phx_params *p) {
+    if (!p) return PHX_E_ARG;
+    phx_default_params(p);
+    p->minlen = minlen;
+    auto lower3 = [](const std::string &t, char *out) {
+        if (t.size() != 3) return false;
+        for (int j = 0; j < 3; j++) { const char ch = (char)(t[(size_t)j] | 0x20); if (code_of(ch) < 0) return false; out[j] = ch; }
+        out[3] = 0;
+        return true;
+    };
+    auto split = [](const char *s) { std::vector<std::string> v; std::string cur; for (; *s; s++) { if (*s == ',') { v.push_back(cur); cur.clear(); } else cur.push_back(*s); } v.push_back(cur); return v; };
+    if (start_codons) {
+        p->n_start = 0;
+        memset(p->start, 0, sizeof(p->start)); memset(p->start_w, 0, sizeof(p->start_w)); memset(p->start_w_text, 0, sizeof(p->start_w_text));
+        double wv[PHX_MAX_CODONS];
+        for (const std::string &item : split(start_codons)) {
+            const size_t colon = item.find(':');
+            if (colon == std::string::npos || item.find(':', colon + 1) != std::string::npos) return PHX_E_PARAM;
+            char cod[4];
+            if (!lower3(item.substr(0, colon), cod)) return PHX_E_PARAM;
+            const std::string wt = item.substr(colon + 1);
+            if (wt.empty() || wt.size() >= sizeof(p->start_w_text[0])) return PHX_E_PARAM;
+            char *end = nullptr;
+            const double w = strtod(wt.c_str(), &end);
+            if (!end || *end || !(w == w)) return PHX_E_PARAM;
+            int at = -1;
+            for (int i = 0; i < p->n_start; i++) if (!strcmp(p->start[i], cod)) at = i; // dict semantics: first place, last weight
+            if (at < 0) { if (p->n_start >= PHX_MAX_CODONS) return PHX_E_PARAM; at = p->n_start++; strcpy(p->start[at], cod); }
+            strcpy(p->start_w_text[at], wt.c_str());
+            wv[at] = w;
+        }
+        if (p->n_start < 1) return PHX_E_PARAM;
+        double mx = wv[0];
+        for (int i = 1; i < p->n_start; i++) mx = wv[i] > mx ? wv[i] : mx;
+        for (int i = 0; i < p->n_start; i++) p->start_w[i] = wv[i] / mx; // file_handling.py:58-62
+    }
+    if (stop_codons) {
+        p->n_stop = 0;
+        memset(p->stop, 0, sizeof(p->stop));
+        for (const std::string &item : split(stop_codons)) {
+            if (p->n_stop >= PHX_MAX_CODONS) return PHX_E_PARAM;
+            if (!lower3(item, p->stop[p->n_stop])) return PHX_E_PARAM;
+            p->n_stop++;
+        }
+    }
+    return check_params(p);
 }
 
 int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
@@ -534,7 +593,7 @@ int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -554,6 +613,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->graphs_enabled = (flags & PHX_CREATE_NO_GRAPH) == 0;
     c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
+    c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
     c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
     c->poison = (flags & PHX_CREATE_POISON) != 0;
     c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
@@ -1089,7 +1149,7 @@ int push_layout(phx_ctx *c) {
 // later kernels then do nothing, and the caller runs again with `learn`.
 int launch_once(phx_ctx *c, bool learn) {
     int rc;
-    c->tapw_valid = false; c->cert_done = false;
+    c->tapw_valid = false; c->cert_done = false; c->exact_done = false; c->exact_genes.clear(); c->exact_failed = 0;
     hipStream_t s = c->stream;
     c->eager_now = c->eager_done && !c->meta0_dirty && !c->tiles_dirty; // the first launch after such an upload only: a repeated or retried run does everything
     c->eager_done = false;
@@ -1155,7 +1215,7 @@ int finish_once(phx_ctx *c) {
     if (ht->class_mask != c->last_mask || ht->lds_need[0] != c->last_lds[0] || ht->lds_need[1] != c->last_lds[1] || ht->lds_need[2] != c->last_lds[2] || ht->lds_need[3] != c->last_lds[3])
         c->graph_valid = false; // the next run launches other solver kernels / LDS sizes
     c->last_mask = ht->class_mask;
-    if (ht->vmax != c->last_vmax) { c->graph_valid = false; c->last_vmax = ht->vmax; } // (k_certify's LDS size is part of the captured launch)
+    c->last_vmax = ht->vmax; // (sizes k_certify's LDS tables; that kernel runs on demand, outside the captured graph)
     for (int k = 0; k < 4; k++) c->last_lds[k] = ht->lds_need[k];
     if (!covered) return kRetry;
     c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
@@ -1269,11 +1329,14 @@ static int ensure_gene_stage(phx_ctx *c, size_t n) {
     return PHX_OK;
 }
 
+static int ensure_exact(phx_ctx *c); // certificate, and the host re-solve of what it leaves open (below, behind the taps it reads)
+
 int phx_download(phx_ctx *c, phx_result *out) {
     if (!c || (!out && c->n > 0)) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rx = ensure_exact(c); if (rx) return rx; }
     int64_t total = 0;
     for (int i = 0; i < c->n; i++) total = std::max<int64_t>(total, c->res[i].gene_off + c->res[i].n_genes);
     { const int rg = ensure_gene_stage(c, (size_t)total); if (rg) return rg; }
@@ -1284,13 +1347,15 @@ int phx_download(phx_ctx *c, phx_result *out) {
     for (int i = 0; i < c->n; i++) {
         const DRes &m = c->res[(size_t)i];
         out[i].status = m.status;
-        out[i].n_genes = m.status < 0 ? 0 : m.n_genes;
+        const auto ex = c->exact_genes.find(i); // solved again on the host: those genes
+        const DGene *src = ex != c->exact_genes.end() ? ex->second.data() : c->h_genes + (size_t)m.gene_off;
+        out[i].n_genes = m.status < 0 ? 0 : (ex != c->exact_genes.end() ? (int32_t)ex->second.size() : m.n_genes);
         out[i].genes = nullptr;
         if (out[i].n_genes > 0) {
             out[i].genes = (phx_gene *)malloc(sizeof(phx_gene) * (size_t)out[i].n_genes);
             if (!out[i].genes) return PHX_E_NOMEM;
             for (int k = 0; k < out[i].n_genes; k++) {
-                const DGene &g = c->h_genes[(size_t)(m.gene_off + k)];
+                const DGene &g = src[k];
                 out[i].genes[k].left = g.left; out[i].genes[k].right = g.right;
                 out[i].genes[k].strand = g.strand; out[i].genes[k].frame = g.frame;
                 out[i].genes[k].score = g.score;
@@ -1305,12 +1370,19 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
     HIPCHK(c, hipSetDevice(c->device));
+    { const int rx = ensure_exact(c); if (rx) return rx; }
+    auto count_of = [&](int i) -> int64_t { // genes of contig i: the host re-solve's where there was one
+        const DRes &m = c->res[(size_t)i];
+        if (m.status < 0) return 0;
+        if (!c->exact_genes.empty()) { const auto ex = c->exact_genes.find(i); if (ex != c->exact_genes.end()) return (int64_t)ex->second.size(); }
+        return m.n_genes;
+    };
     int64_t total = 0, hi = 0;
-    for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; total += m.status < 0 ? 0 : m.n_genes; hi = std::max<int64_t>(hi, m.gene_off + m.n_genes); }
+    for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; total += count_of(i); hi = std::max<int64_t>(hi, m.gene_off + m.n_genes); }
     if (total_out) *total_out = total;
     if (!genes) { // size query
         int64_t o = 0;
-        for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; offsets[i] = o; status[i] = m.status; o += m.status < 0 ? 0 : m.n_genes; }
+        for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; offsets[i] = o; status[i] = m.status; o += count_of(i); }
         if (c->n >= 0 && offsets) offsets[c->n] = o;
         return PHX_OK;
     }
@@ -1324,9 +1396,11 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     int64_t o = 0;
     for (int i = 0; i < c->n; i++) {
         const DRes &m = c->res[(size_t)i];
-        const int64_t k = m.status < 0 ? 0 : m.n_genes;
+        const int64_t k = count_of(i);
         offsets[i] = o; status[i] = m.status;
-        if (k) memcpy(genes + o, &c->h_genes[(size_t)m.gene_off], sizeof(phx_gene) * (size_t)k);
+        const DGene *src = &c->h_genes[(size_t)m.gene_off];
+        if (!c->exact_genes.empty()) { const auto ex = c->exact_genes.find(i); if (ex != c->exact_genes.end()) src = ex->second.data(); }
+        if (k) memcpy(genes + o, src, sizeof(phx_gene) * (size_t)k);
         o += k;
     }
     offsets[c->n] = o;
@@ -1360,8 +1434,19 @@ int phx_certified(phx_ctx *c, int8_t *cert) {
     if (!c || (!cert && c->n > 0)) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!c->ran) return PHX_E_STATE;
-    { const int rc = ensure_cert(c); if (rc) return rc; }
+    { const int rc = c->exact ? ensure_exact(c) : ensure_cert(c); if (rc) return rc; }
     for (int i = 0; i < c->n; i++) { const DRes &m = c->res[(size_t)i]; cert[i] = (int8_t)(!c->certify ? -1 : (m.status < 0 ? 1 : m.cert)); }
+    return PHX_OK;
+}
+
+int phx_set_exact(phx_ctx *c, int on) {
+    if (!c) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
+    if (!on) { // the device's own lists again, for every contig
+        for (auto &kv : c->exact_genes) if (c->res && kv.first < c->n) c->res[(size_t)kv.first].cert = 0;
+        c->exact_genes.clear(); c->exact_done = false;
+    }
+    c->exact = on != 0;
     return PHX_OK;
 }
 
@@ -1422,7 +1507,7 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     out->sssp_kernel = m.sssp_mode;
     out->sssp_handed_back = m.sssp_why > 0 ? m.sssp_why : 0;
     out->tie = m.tie;
-    out->certified = c->certify ? m.cert : -1;
+    out->certified = c->certify ? (c->exact_genes.count(contig) ? 2 : m.cert) : -1;
     for (int i = 0; i < 28; i++) { out->rbs_background_count[i] = m.bg[i]; out->rbs_training_count[i] = m.tr[i]; }
     for (int i = 0; i < 4; i++) { out->gc_max_count[i] = i ? m.pmax[i] : 0u; out->gc_min_count[i] = i ? m.pmin[i] : 0u; }
     out->gc_count = m.gc;
@@ -1678,6 +1763,72 @@ int phx_tap_dist(phx_ctx *c, int32_t contig, uint64_t *dist_limbs, int64_t cap_w
 }
 
 // ---- the solver alone ----
+} // extern "C" (the replay is C++)
+#include "phx_exact.inc"
+extern "C" {
+
+// everything the replay reads of contig i, through the taps (exact device output) + the solver's own integers and the bases
+static int exact_fetch(phx_ctx *c, int32_t contig, ExactIn &in) {
+    int rc;
+    if ((rc = phx_tap_globals(c, contig, &in.gl))) return rc;
+    in.L = (int)in.gl.L;
+    in.nl = in.gl.n_limbs;
+    in.nd.resize((size_t)std::max(in.gl.n_node, 0)); in.ed.resize((size_t)std::max(in.gl.n_edge, 0)); in.orf.resize((size_t)std::max(in.gl.n_orf, 0));
+    in.gcc.resize((size_t)in.L); in.base.resize((size_t)in.L);
+    if ((rc = phx_tap_nodes(c, contig, in.nd.data()))) return rc;
+    if ((rc = phx_tap_edges(c, contig, in.ed.data()))) return rc;
+    if ((rc = phx_tap_orfs(c, contig, in.orf.data()))) return rc;
+    if ((rc = phx_tap_positions(c, contig, nullptr, in.gcc.data(), nullptr, nullptr))) return rc;
+    const DMeta &m = c->meta[(size_t)contig];
+    in.ewi.resize(in.ed.size());
+    if (!in.ewi.empty()) HIPCHK(c, hipMemcpy(in.ewi.data(), (long long *)c->b_ew.p + m.edge_off, in.ewi.size() * 8, hipMemcpyDeviceToHost));
+    const size_t L = (size_t)in.L;
+    if (L && c->packed) {
+        std::vector<uint8_t> pk((L + 1) / 2);
+        HIPCHK(c, hipMemcpy(pk.data(), (const uint8_t *)c->b_ascii.p + (m.off >> 1), pk.size(), hipMemcpyDeviceToHost));
+        static const uint8_t map4[4] = {0, 1, 2, 3}; // nibble code a0 c1 t2 g3
+        for (size_t p = 0; p < L; p++) { const unsigned nb = (pk[p >> 1] >> (4 * (p & 1))) & 15u; in.base[p] = (nb & 4u) ? (uint8_t)4 : map4[nb & 3u]; }
+    } else if (L) {
+        std::vector<uint8_t> asc(L);
+        HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < L; p++) { switch (asc[p] | 0x20) { case 'a': in.base[p] = 0; break; case 'c': in.base[p] = 1; break; case 't': in.base[p] = 2; break; case 'g': in.base[p] = 3; break; default: in.base[p] = 4; } }
+    }
+    return PHX_OK;
+}
+
+// The certificate, and for every contig it leaves open the reference's own arithmetic on the host (one worker thread per contig, at
+// most 32): phx_download* and phx_certified call this; its results replace the contig's genes.
+static int ensure_exact(phx_ctx *c) {
+    if (!c->certify || c->n == 0) return PHX_OK;
+    { const int rc = ensure_cert(c); if (rc) return rc; }
+    if (!c->exact || c->exact_done) return PHX_OK;
+    std::vector<int> todo;
+    for (int i = 0; i < c->n; i++) if (c->res[(size_t)i].status >= 0 && c->res[(size_t)i].cert == 0) todo.push_back(i);
+    if (!todo.empty()) {
+        std::vector<ExactIn> in(todo.size());
+        std::vector<ExactOut> out(todo.size());
+        for (size_t k = 0; k < todo.size(); k++) { const int rc = exact_fetch(c, todo[k], in[k]); if (rc) return rc; }
+        const phx_params par = c->params;
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (;;) { const size_t k = next.fetch_add(1); if (k >= todo.size()) return; exact_solve(in[k], par, out[k]); } };
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if (nt > 32) nt = 32;
+        if (nt > todo.size()) nt = (unsigned)todo.size();
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) { try { th.emplace_back(work); } catch (...) { break; } }
+        work();
+        for (std::thread &t : th) t.join();
+        for (size_t k = 0; k < todo.size(); k++) {
+            if (out[k].failed) { c->exact_failed++; continue; }
+            c->exact_genes[todo[k]] = std::move(out[k].genes);
+            c->res[(size_t)todo[k]].cert = 2;
+        }
+    }
+    c->exact_done = true;
+    return PHX_OK;
+}
+
 int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs, int32_t n_limbs,
               int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path, uint64_t *dist_limbs) {
     if (!c || V < 2 || E < 0 || (E > 0 && (!src || !dst || !w_limbs)) || !n_path) return PHX_E_ARG;

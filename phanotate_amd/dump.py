@@ -214,3 +214,35 @@ def decimal_weights(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05", flag
                 w = _overlap(ps - pd + 3, diff, pst)
         weight.append(w)
     return nd, ed, weight
+
+
+def python_resolve(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
+    """The genes of contig i as the reference's own integers give them, in Python: Decimal weights of the edges the device flagged
+    (decimal_weights), the solver's in-place Bellman-Ford over Graph.iteredges order with a strict '<' (phanotate.py:56-64;
+    tests/golden/make_golden.py:100-133) in python ints.  The library does the same below the C-ABI (csrc/phx_exact.inc); this is the
+    cross-check the tests hold it against.  Returns a list of (left, right, strand, frame, score)."""
+    nd, ed, wdec = decimal_weights(ann, i, seq, start_codons, flagged_only=True)
+    V = len(nd)
+    esrc, edst = ed["src"].tolist(), ed["dst"].tolist()
+    E = [(esrc[k], edst[k], int(wdec[k] * 1000), k) for k in edge_order(nd, ed)]
+    dist, par = [None] * V, [-1] * V
+    dist[V - 2] = 0
+    for _ in range(V + 1):
+        ch = False
+        for u, v, w, k in E:
+            du = dist[u]
+            if du is not None and (dist[v] is None or du + w < dist[v]):
+                dist[v] = du + w; par[v] = k; ch = True
+        if not ch:
+            break
+    if V < 2 or dist[V - 1] is None:
+        return []
+    pe, v = [], V - 1
+    while v != V - 2:
+        pe.append(par[v]); v = esrc[par[v]]
+    pe.reverse()  # edges source -> target; shortest_path[1:] pairwise = every second edge (phanotate.py:65-76)
+    out = []
+    for k in pe[1::2]:
+        a, b_ = int(ed[k]["src"]), int(ed[k]["dst"])
+        out.append((int(nd[a]["pos"]), int(nd[b_]["pos"]) + 2, -1 if nd[a]["frame"] < 0 else 1, int(nd[a]["frame"]), float(ed[k]["w"])))
+    return out

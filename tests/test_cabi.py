@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_errors():
     lib = _lib.lib()
-    assert lib.phx_version() == 300
+    assert lib.phx_version() == 400
     assert b"no CPU path" in lib.phx_strerror(-10)
     assert lib.phx_strerror(-2)
 
@@ -49,7 +49,8 @@ def test_no_cpu_fallback():
 def test_bad_params_rejected():
     lib = _lib.lib()
     h = C.c_void_p()
-    bads = [pa.make_params(minlen=3)]
+    bads = [pa.make_params()]
+    bads[0].minlen = 3
     for field, text in (("start", b"anx"), ("stop", b"ta"), ("start", b"atgc")):  # a bad letter, a short codon, a 4-letter codon without NUL
         q = pa.make_params()
         C.memmove(C.addressof(getattr(q, field)[0]), text + b"\0" * (4 - len(text)), 4)
@@ -59,7 +60,7 @@ def test_bad_params_rejected():
         assert lib.phx_create_ex(C.byref(bad), 0, None, 1, C.byref(h)) == -14
     assert lib.phx_create_ex(C.byref(pa.make_params()), 0, None, 1 << 20, C.byref(h)) == -1  # unknown flag
     # the binding refuses them before they reach the library (the reference would keep such codons as keys that never match)
-    for kw in (dict(start_codons="anx:1"), dict(stop_codons="ta"), dict(start_codons="atgc:1"), dict(start_codons="atg")):
+    for kw in (dict(start_codons="anx:1"), dict(stop_codons="ta"), dict(start_codons="atgc:1"), dict(start_codons="atg"), dict(minlen=3)):
         with pytest.raises(ValueError):
             pa.make_params(**kw)
 

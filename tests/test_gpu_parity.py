@@ -1109,10 +1109,13 @@ def test_certificate_kernel_equals_its_python_statement(pa):
 
 
 def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, oracle):
-    """The host leg of the guarantee: a contig the device does not certify is solved again on the reference's Decimal-derived
-    integers (Annotator.resolve_uncertified: dump.decimal_weights + the in-order Bellman-Ford in python ints) and its genes are
-    replaced.  With the bounds inflated (cert_tight) that happens to most contigs of a batch: the result must equal the certified
-    run's, byte for byte in the integers, and the oracle's."""
+    """The host leg of the guarantee, below the C-ABI: a contig the device does not certify is solved again inside phx_download* on
+    the reference's Decimal-derived integers (csrc/phx_exact.inc: the Decimal chain replayed by phx_dec.c + the in-order Bellman-Ford
+    on exact integers) and its genes are replaced; phx_certified reports 2.  With the bounds inflated (cert_tight) that happens to
+    most contigs of a batch: the result must equal the certified run's, byte for byte in the integers, the oracle's, and what the
+    same replay gives in Python (dump.python_resolve: decimal.Decimal itself + python ints)."""
+    from phanotate_amd import dump
+
     seqs = _fuzz_contigs(40, 91, 9000) + [pa.synth_contig(4100, 20000).decode()]
     plain = pa.Annotator()
     want = plain.annotate_flat(seqs)
@@ -1120,18 +1123,45 @@ def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, ora
     plain.close()
     tight = pa.Annotator(flags=("cert_tight",))
     got = tight.annotate_flat(seqs)
-    assert len(tight.resolved) >= 10
+    assert len(tight.resolved) >= 10 and tight.resolved == [int(i) for i in np.nonzero(tight.certified() == 2)[0]]
+    assert (tight.certified() != 0).all()
     assert got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()
     for f in ("left", "right", "strand", "frame"):
         assert np.array_equal(got[2][f], want[2][f]), f
     np.testing.assert_allclose(got[2]["score"], want[2]["score"], rtol=1e-12)
     raw = tight.download_flat(exact=False)  # what the device itself reported: the same here
-    assert raw[2].tobytes() == want[2].tobytes()
+    assert raw[2].tobytes() == want[2].tobytes() and tight.resolved == []
+    assert (tight.certified() != 2).all()
+    again = tight.download_flat()           # and the guarantee is back on
+    assert again[2].tobytes() == got[2].tobytes() and len(tight.resolved) >= 10
     for i in tight.resolved[:12]:
         o = oracle.run(seqs[i])
         g = got[2][got[1][i] : got[1][i + 1]]
         assert np.array_equal(g["left"], o["gene_left"]) and np.array_equal(g["right"], o["gene_right"]) and np.array_equal(g["frame"], o["gene_frame"].astype(np.int32))
+        py = dump.python_resolve(tight, i, seqs[i])
+        assert [(int(x["left"]), int(x["right"]), int(x["strand"]), int(x["frame"]), float(x["score"])) for x in g] == py, i
+    # the struct-of-pointers download goes through the same substitution
+    per = tight.download()
+    for i in tight.resolved[:12]:
+        assert per[i][1].tobytes() == got[2][got[1][i] : got[1][i + 1]].tobytes()
     tight.close()
+    # a context that must not spend host time: the device's lists, cert stays 0
+    ne = pa.Annotator(flags=("cert_tight", "no_exact"))
+    r = ne.annotate_flat(seqs)
+    assert ne.resolved == [] and (ne.certified() == 0).sum() >= 10 and r[2].tobytes() == want[2].tobytes()
+    ne.close()
+
+
+def test_contigs_without_a_graph_are_certified(pa):
+    """A batch whose contigs have no ORF at all (two nodes: source and target) launches no k_certify for their integer class: such
+    contigs count as certified (nothing to decide) and are never handed to the host re-solve."""
+    seqs = ["acgtacgtac" * 3, "t" * 80, "ca" * 30]
+    ann = pa.Annotator()
+    st, offs, genes = ann.annotate_flat(seqs)
+    assert st.tolist() == [0, 0, 0] and len(genes) == 0
+    assert ann.certified().tolist() == [1, 1, 1] and ann.resolved == []
+    assert [ann.globals(i).n_node for i in range(3)] == [2, 2, 2]
+    ann.close()
 
 
 def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
