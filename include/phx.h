@@ -120,8 +120,11 @@ typedef struct phx_edge { /* in-edge list order of the device graph: grouped by 
     int32_t src, dst;     /* device node ids (position-sorted; source = V-2, target = V-1) */
     double w;             /* Decimal weight of the reference, in fp64 (the solver adds trunc(w * 1000), edges.py:22: the device keeps
                            * that integer, the tap recomputes w and checks the two against each other) */
-    int32_t inexact;      /* 1: trunc(Decimal(w) * 1000) may differ from trunc(w * 1000) (the eps_e > 0 of phx_certified) */
+    int32_t inexact;      /* 1: the reference's integer W* = trunc(Decimal(w) * 1000) is not known to equal the solver's W = trunc(w * 1000).
+                           * Before the certificate has been asked for (phx_certified / phx_download* / phx_tap_globals): the verdict of the fp64
+                           * pipeline; after it: of the double-double evaluation (csrc/phx_refine.inc), which clears most flags and leaves, for the rest, */
     int32_t pad;
+    double d1, d2, err;   /* W* in [W + D - eps, W + D + eps], D = d1 + d2 (both integer-valued), eps = 0 if err == 0 else floor(err) + 1 (err = inf: unknown) */
 } phx_edge;
 
 typedef struct phx_globals {

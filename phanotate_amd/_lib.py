@@ -47,7 +47,7 @@ GENE_DT = np.dtype([("left", "i4"), ("right", "i4"), ("strand", "i4"), ("frame",
 ORF_DT = np.dtype([("start", "i4"), ("stop", "i4"), ("frame", "i4"), ("length", "i4"), ("rbs", "i4"), ("startidx", "i4"), ("group", "i4"),
                    ("hist", "i4", (9,)), ("pstop", "f8"), ("weight_rbs", "f8"), ("S", "f8"), ("weight", "f8")], align=True)
 NODE_DT = np.dtype([("pos", "i4"), ("type", "i1"), ("frame", "i1"), ("pad", "i2"), ("other", "i4"), ("refidx", "i4"), ("o", "f8")], align=True)
-EDGE_DT = np.dtype([("src", "i4"), ("dst", "i4"), ("w", "f8"), ("inexact", "i4"), ("pad", "i4")], align=True)
+EDGE_DT = np.dtype([("src", "i4"), ("dst", "i4"), ("w", "f8"), ("inexact", "i4"), ("pad", "i4"), ("d1", "f8"), ("d2", "f8"), ("err", "f8")], align=True)
 
 _lib = None
 

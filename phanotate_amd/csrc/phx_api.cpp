@@ -152,6 +152,7 @@ struct phx_ctx {
     std::vector<DTNode> h_tnode;               // host copy for the node tap
     bool has_trna = false;
     DevBuf b_cint, b_csig; // scratch of k_certify (per node)
+    DevBuf b_eref;         // k_refine -> k_certify: bounds on the reference's integers, per edge (allocated when a certificate is first asked for)
     bool certify = true;   // phx_certified works (PHX_CREATE_NO_CERTIFY: it reports -1 and the scratch is not allocated)
     bool cert_done = false; // k_certify has run on the results the context holds
     bool exact = true;       // phx_download* solve uncertified contigs again on the host (PHX_CREATE_NO_EXACT: they do not)
@@ -284,6 +285,7 @@ void build_dparams(const phx_params *p, DParams *d) {
     d->minlen = p->minlen;
     d->n_start = p->n_start;
     for (int i = 0; i < p->n_start; i++) d->start_w[i] = p->start_w[i];
+    { dec_t q[PHX_MAX_CODONS]; dec_start_weights(p->n_start, p->start_w_text, p->start_w, q); for (int i = 0; i < p->n_start; i++) dec_to_dd(&q[i], &d->sw_hi[i], &d->sw_lo[i]); }
     auto codon_code = [](const char *c) { return code_of(c[0]) | (code_of(c[1]) << 2) | (code_of(c[2]) << 4); };
     auto rc_code = [](int ci) { // reverse complement of a codon code
         int c0 = ci & 3, c1 = (ci >> 2) & 3, c2 = (ci >> 4) & 3;
@@ -403,6 +405,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->esrcf = nullptr; b->ewf = nullptr;
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->cint = (int32_t *)c->b_cint.p; b->csig = (uint64_t *)c->b_csig.p; b->cert_scale = c->cert_scale;
+    b->eref = (DERef *)c->b_eref.p;
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
     b->gpack = gene_pack(c) ? 1 : 0;
@@ -685,7 +688,7 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
+    DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -1412,12 +1415,14 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
 static int ensure_cert(phx_ctx *c) {
     if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    { const int re = ensure(c, c->b_eref, ((size_t)c->tot_edge + 1) * sizeof(DERef)); if (re) return re; }
     DBatch b;
     fill_batch(c, &b);
     int nlm = 0;
     for (int k = 0; k < 4; k++) nlm |= ((c->last_mask >> (4 * k)) & 15) ? 1 << k : 0;
     {
         StageTimer t(c, ST_CERTIFY);
+        phxk_refine(&b, c->stream); // the flagged edges once more in double-double: flags cleared or bounds in b_eref
         phxk_certify(&b, nlm, c->cert_wide ? -1 : c->last_vmax, c->stream);
         phxk_results(&b, c->stream);
     }
@@ -1715,6 +1720,9 @@ int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
     // the records the solver read: source | off-path << 30 | inexact << 31, and the integer trunc(w * 1000) in the encoding of ew_encode
     HIPCHK(c, hipMemcpy(esrci.data(), (uint32_t *)c->b_esrc.p + m.edge_off, E * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(ewi.data(), (long long *)c->b_ew.p + m.edge_off, E * 8, hipMemcpyDeviceToHost));
+    const bool have_ref = c->certify && c->cert_done && c->b_eref.p; // k_refine has looked at the flagged edges of this run
+    std::vector<DERef> eref(have_ref ? E : 0);
+    if (have_ref) HIPCHK(c, hipMemcpy(eref.data(), (DERef *)c->b_eref.p + m.edge_off, E * sizeof(DERef), hipMemcpyDeviceToHost));
     for (size_t v = 0; v < V; v++)
         for (uint32_t e = in_off[v]; e < in_off[v + 1]; e++) {
             esrc[e] = ESRC_NODE(esrc[e]); // (the tap variant carries the off-path flag of a source-node edge)
@@ -1732,6 +1740,8 @@ int phx_tap_edges(phx_ctx *c, int32_t contig, phx_edge *out) {
                 c->err = msg; return PHX_E_STATE;
             }
             out[e].inexact = (int32_t)(esrci[e] >> 31);
+            out[e].pad = 0; out[e].d1 = 0; out[e].d2 = 0; out[e].err = 0;
+            if (have_ref && out[e].inexact) { out[e].d1 = eref[e].d1; out[e].d2 = eref[e].d2; out[e].err = eref[e].err; }
         }
     return PHX_OK;
 }

@@ -588,6 +588,19 @@ int phx_repr_double(double x, char *out, int cap) { /* float_repr_style 'short' 
     return (int)(q - out);
 }
 
+void dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out) {
+    static __thread dec_t t[16];
+    if (n > 16) n = 16;
+    int mx = 0;
+    for (int i = 0; i < n; i++) {
+        char buf[48];
+        if (texts && texts[i][0]) { if (dec_from_str(&t[i], texts[i])) dec_from_i64(&t[i], 0); }
+        else { phx_repr_double(w[i], buf, sizeof buf); dec_from_str(&t[i], buf); }
+        if (dec_cmp(&t[i], &t[mx]) > 0) mx = i;
+    }
+    for (int i = 0; i < n; i++) if (dec_div(&out[i], &t[i], &t[mx], DEC_PREC)) dec_from_i64(&out[i], 0);
+}
+
 /* ------------------------------------------------------------------------------------------------ test hook (tests/test_dec.py) */
 /* op: "add" "sub" "mul" "div" "pow" "ln" "exp" "str" (a alone) "float" (a = repr of a double -> Decimal(float)) "repr" (repr(float(a)))
  * "trunc1000" (int(a * 1000) as decimal text); result text in out.  Returns the length or a negative error. */

@@ -55,6 +55,9 @@ void dec_to_dd(const dec_t *a, double *hi, double *lo);
 /* repr(float) of Python 3 (float_repr_style 'short': the shortest digit string that rounds back to x, the closest such one), as the
  * text Decimal(str(x)) is built from (orfs.py:126).  Finite x only.  Returns the length. */
 int phx_repr_double(double x, char *out, int cap);
+/* file_handling.py:58-62: Decimal(weight) / max over n start codons.  texts[i]: the weight as written, or "" = the shortest decimal
+ * that reads back as w[i].  out[i]: the 28-digit quotients. */
+void dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out);
 int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *out, int cap); /* test hook, see include/phx.h */
 
 #ifdef __cplusplus

@@ -68,6 +68,7 @@ struct DParams { // device copy of phx_params + derived tables
     double start_w[PHX_MAX_CODONS];
     uint8_t cls_tab[72];  // codon code (c0 | c1<<2 | c2<<4) -> cls byte; entry 64 = no codon (0)
     uint8_t atg_tab[72];  // bit0: codon == 'atg', bit1: codon == 'cat', bits 2..5: start-codon index (as cls_tab bits 3..6); entry 64 = 0
+    double sw_hi[PHX_MAX_CODONS], sw_lo[PHX_MAX_CODONS]; // the reference's start weights, Decimal(text) / max rounded to 28 digits (file_handling.py:58-62), as double-doubles (k_refine)
 };
 
 struct DOrf { // what the scan knows about an ORF: one 16-byte store by k_orf<true>
@@ -164,6 +165,12 @@ struct DRes {
     int32_t status, n_genes;
     int64_t gene_off;
     int32_t cert, tie; // DMeta.cert, DMeta.tie
+};
+
+// k_refine -> k_certify, per edge that is still flagged "inexact": the reference's integer W* lies in [W + D - eps, W + D + eps], D = d1 + d2
+// (two integer-valued doubles), eps = 0 if err == 0, else floor(err) + 1; err = infinity: nothing is known (the contig is not certified)
+struct DERef {
+    double d1, d2, err;
 };
 
 struct DTile {
@@ -279,6 +286,7 @@ struct DBatch {
     int64_t tie_cap;
     int32_t *cint;       // scratch of k_certify: 5 words per node (tree edge, two (link, kappa) pairs),
     uint64_t *csig;      //   2 x dist_stride limbs per node (sigma, double-buffered)
+    DERef *eref;         // per edge (sparse: written for the edges that stay flagged): bounds on W* - W from k_refine
     double cert_scale;   // factor on k_certify's error bounds (1; PHX_CREATE_CERT_TIGHT: 2^36, so that the tests see uncertified contigs)
     int32_t defer_overlap; // 1: k_edges<true> queues the overlap edges of a workgroup and evaluates their weights after the neighbour scan (needs node ids < 2^21)
     // output
@@ -313,6 +321,7 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream);
 int phxk_sssp_wave_ok(int n_limbs); // limb classes the wavefront-per-contig kernel is built for
 void phxk_sssp(const DBatch *b, int n_limbs, int mode, size_t lds_bytes, void *stream);
 void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
+void phxk_refine(const DBatch *b, void *stream);  // before k_certify: the flagged edges once more in double-double (flags cleared / DBatch.eref)
 void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream); // after k_inorder: DMeta.cert
 void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them

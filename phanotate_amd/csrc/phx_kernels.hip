@@ -18,6 +18,7 @@
 //                  k_sssp_lds<NL> (workgroup / contig),     phx_sssp.inc       integers; path -> genes phanotate.py:65-76,
 //                  k_sssp<NL> + k_path<NL> (global memory)                     locus.py:29-37
 //                  k_inorder (ties between equal-length paths)  phx_inorder.inc    relaxation order of the reference's solver
+//                  k_refine (flagged edges in double-double) phx_refine.inc    functions.py:26-46,286-301: bounds on the reference's integers
 //                  k_certify (fp64 vs Decimal weights)      phx_certify.inc    edges.py:17-23: the integers the reference solves on
 //
 // No MFMA anywhere: the path has no dense contraction.  All integer outputs are
@@ -166,6 +167,7 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 #include "phx_layout.inc"
 #include "phx_sssp_wave.inc"
 #include "phx_inorder.inc"
+#include "phx_refine.inc"
 #include "phx_certify.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -258,6 +260,8 @@ void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream) {
     if (nl_mask & 4) launch_certify<8>(b, vcap, s);
     if (nl_mask & 8) launch_certify<17>(b, vcap, s);
 }
+
+void phxk_refine(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_refine, dim3(b->n_contig), dim3(RF_T), 0, (hipStream_t)stream, *b); }
 
 void phxk_gene_pack(const DBatch *b, void *stream) {
     const unsigned g = (unsigned)((b->n_contig + LMB_T - 1) / LMB_T);

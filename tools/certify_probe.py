@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Prototype of the Decimal-vs-fp64 certificate, run on the GPU box:   python tools/certify_probe.py [n] [seed]
 
-libphx solves on W = trunc(fp64(w) * 1000), the reference on W* = trunc(Decimal(w) * 1000).  With a per-edge bound
-|W* - W| <= eps_e, the device's path P is the reference's path whenever a dual certificate holds (LP duality on the scenario
+libphx solves on W = trunc(fp64(w) * 1000), the reference on W* = trunc(Decimal(w) * 1000).  With per-edge bounds
+lo_e <= W* - W <= hi_e (k_refine, phx_refine.inc: the flagged edges once more in double-double + the error bound of the reference's own
+28-digit chain), the device's path P is the reference's path whenever a dual certificate holds (LP duality on the scenario
 "P's edges as heavy, every other edge as light as the bounds allow"):
-  tree = the device's shortest-path tree (P = its path to the target), sigma[v] = signed sum of eps along the tree path to v
-  (+ on P, - off P), kappa[v] = last node on that path whose tree edge has eps > 0.  For every non-tree edge e = (u -> v) of a
-  reached u:   r(e) + sigma[u] - sigma[v] - eps_e > 0          (r = d[u] + W_e - d[v], exact)
-  or  r(e) == 0 and eps_e == 0 and kappa[u] == kappa[v]        (a tie that is exact in the reference's integers too).
-The probe checks (1) that eps_e really bounds |W* - W| on every edge (W* replayed by phanotate_amd/dump.py), (2) how many
-contigs the certificate covers, (3) that for the covered ones the Decimal-derived in-order solve gives the same path."""
+  tree = the device's shortest-path tree (P = its path to the target), sigma[v] = sum of (hi on P, lo off P) along the tree path to v,
+  kappa[v] = last node on that path whose tree edge is flagged.  For every non-tree edge e = (u -> v) of a reached u:
+  r(e) + sigma[u] - sigma[v] + lo_e > 0                        (r = d[u] + W_e - d[v], exact)
+  or  r(e) == 0 and e not flagged and kappa[u] == kappa[v]     (a tie that is exact in the reference's integers too).
+The probe checks (1) that the bounds really hold W* on every edge (W* replayed by phanotate_amd/dump.py with Python's decimal), (2) how
+many contigs the certificate covers, (3) that for the covered ones the Decimal-derived in-order solve gives the same path."""
 import math
 import os
 import sys
@@ -25,39 +26,37 @@ from fuzz_gpu import make
 from phanotate_amd.dump import decimal_weights
 
 
-def eps_of(w, inexact, scale=1.0):
-    """Bound on |trunc(Decimal w * 1000) - trunc(fp64 w * 1000)|: 0 for an edge the device did not flag (its p = w * 1000 is farther
-    from the next integer than its error bound), else from the integer the solver uses — cert_eps in phx_certify.inc, the same
-    operations in the same order."""
-    if not inexact:
-        return 0
-    t = math.trunc(w * 1000.0)
-    a = float(abs(t)) + 1.0 if abs(t) < 2 ** 62 else abs(float(t))
-    ex = abs(math.frexp(a)[1])
-    err = a * float(ex + 8) * (scale * 2.0 ** -46)
-    return int(math.floor(err)) + 1
+def bounds_of(ed):
+    """Per edge (lo, hi) with lo <= W* - W <= hi as the device states them after k_refine (phx_refine.inc; the edge tap's inexact, d1, d2,
+    err): (0, 0) for an edge whose flag is cleared, else D -+ eps with D = d1 + d2 and eps = 0 if err == 0 else floor(err) + 1;
+    None where nothing is known (err = inf)."""
+    out = []
+    for f, d1, d2, err in zip(ed["inexact"].tolist(), ed["d1"].tolist(), ed["d2"].tolist(), ed["err"].tolist()):
+        if not f:
+            out.append((0, 0))
+        elif not err < 1e290:
+            out.append(None)
+        else:
+            D = int(d1) + int(d2)
+            eps = 0 if err == 0 else int(math.floor(err)) + 1
+            out.append((D - eps, D + eps))
+    return out
 
 
-def flag_of(w, scale=1.0):
-    """The device's inexact flag, restated (cert_eps_is_zero_fast, phx_kernels.hip)."""
-    if w == -20.0:
-        return 0  # the tRNA edge: a constant in the reference too (functions.py:509)
-    p = w * 1000.0
-    a = abs(p)
-    if a < 2.0 ** 52:
-        f = a - abs(float(math.trunc(p)))
-        if min(f, 1.0 - f) > a * (60.0 * (scale * 2.0 ** -46)):
-            return 0
-    return 1
+def device_int(w):
+    """The integer the solver adds for an edge whose tapped fp64 weight is w (ew_encode, phx_kernels.hip)."""
+    return int(math.trunc(w * 1000.0))
 
 
-def certify(nd, ed, dist, path, scale=1.0, repair=True):
-    """The certificate of phx_certify.inc in python ints.  repair=False: the form of k_certify_wide (no corrections)."""
+def certify(nd, ed, dist, path, repair=True, ties=None):
+    """The certificate of phx_certify.inc in python ints, on the bounds the device states (bounds_of).  repair=False: the form of
+    k_certify_wide (no corrections).  ties: the contig has equal-length alternatives (phx_globals.tie != 0): a flagged edge into a node
+    off the path must then keep slack."""
     V = len(nd)
     src, dst = ed["src"].tolist(), ed["dst"].tolist()
-    W = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
+    W = [device_int(float(x)) for x in ed["w"]]
     flags = ed["inexact"].tolist()
-    eps = [eps_of(float(x), f, scale) for x, f in zip(ed["w"], flags)]
+    bnd = bounds_of(ed)
     on_path_edge = {}
     for a, b in zip(path[:-1], path[1:]):
         on_path_edge[b] = a
@@ -87,9 +86,11 @@ def certify(nd, ed, dist, path, scale=1.0, repair=True):
             if sigma[u] is None:
                 nxt.append(v)
                 continue
-            sign = 1 if (v in onP and on_path_edge.get(v) == u) else -1
-            sigma[v] = sigma[u] + sign * eps[k]
-            kappa[v] = v if eps[k] > 0 else kappa[u]
+            if flags[k] and bnd[k] is None:
+                return "tree edge %d without bounds" % k, 0
+            on = v in onP and on_path_edge.get(v) == u
+            sigma[v] = sigma[u] + (bnd[k][1] if on else bnd[k][0])  # as heavy as allowed on the path, as light off it
+            kappa[v] = v if flags[k] else kappa[u]
         if len(nxt) == len(pending):
             return "tree cycle", 0
         pending = nxt
@@ -108,19 +109,37 @@ def certify(nd, ed, dist, path, scale=1.0, repair=True):
             r = dist[u] + W[k] - dist[v]
             if r < 0:
                 return "negative reduced cost", 0
-            r0 = 0 if is_tree else r + sigma[u] - sigma[v] - eps[k]
+            if flags[k] and bnd[k] is None and not is_tree:
+                return "edge %d without bounds" % k, 0
+            r0 = 0 if is_tree else r + sigma[u] - sigma[v] + bnd[k][0]
             need = delta[u] - r0
             if v in onP:
-                if not (need < 0 or (r == 0 and eps[k] == 0 and kappa[u] == kappa[v] and delta[u] == 0)):
-                    return "edge %d into the path: r=%d r0=%d eps=%d delta[u]=%d" % (k, r, r0, eps[k], delta[u]), 0
+                if not (need < 0 or (r == 0 and not flags[k] and kappa[u] == kappa[v] and delta[u] == 0)):
+                    return "edge %d into the path: r=%d r0=%d bounds=%s delta[u]=%d" % (k, r, r0, bnd[k], delta[u]), 0
+            elif need == 0:
+                if flags[k] and ties and not is_tree:
+                    return "edge %d off the path: no slack on a flagged edge of a contig with ties" % k, 0
             elif need > delta[v]:
                 if not repair or need > 60000:
-                    return "edge %d off the path: r=%d r0=%d eps=%d" % (k, r, r0, eps[k]), 0
+                    return "edge %d off the path: r=%d r0=%d bounds=%s" % (k, r, r0, bnd[k]), 0
                 delta[v] = need
                 changed = True
         if not changed:
             return "", 1
     return "corrections do not settle", 0
+
+
+def bounds_hold(ed, wdec):
+    """The soundness of what the device states: for every edge the reference's integer W* = int(Decimal weight * 1000) lies inside the
+    bounds (== W where the flag is cleared).  wdec: dump.decimal_weights' Decimal weights in tap order.  Returns the violating edges."""
+    bad = []
+    for k, (w, b) in enumerate(zip(ed["w"].tolist(), bounds_of(ed))):
+        if b is None:
+            continue
+        d = int(wdec[k] * 1000) - device_int(w)
+        if not (b[0] <= d <= b[1]):
+            bad.append((k, w, d, b))
+    return bad
 
 
 def main():
@@ -133,33 +152,29 @@ def main():
         if len(s) <= 12000 and not set(s.lower()) - set("acgt"):
             seqs.append(s)
     seqs += [pa.synth_contig(2000 + k, 50000).decode() for k in range(max(2, n // 10))]
-    ann = pa.Annotator()
+    ann = pa.Annotator(flags=("no_exact",))
     t0 = time.time()
-    n_ok = n_cert = n_same = n_diff = bad_eps = n_edges = n_inexact = ties_cert = 0
+    n_ok = n_cert = n_same = n_diff = bad_b = n_edges = n_flag = n_eps = ties_cert = 0
     reasons = []
     for b0 in range(0, len(seqs), 50):
         part = seqs[b0 : b0 + 50]
-        res = ann.annotate(part)
-        for i, (status, genes) in enumerate(res):
+        ann.upload(part); ann.run()
+        cert = ann.certified()
+        for i in range(len(part)):
             gl = ann.globals(i)
-            if status < 0 or gl.n_node <= 2:
+            if gl.status < 0 or gl.n_node <= 2:
                 continue
             n_ok += 1
             nd, ed, wdec = decimal_weights(ann, i, part[i])
-            Wref = [int(w * 1000) for w in wdec]
-            Wdev = [int(math.trunc(float(x) * 1000.0)) for x in ed["w"]]
-            for k in range(len(ed)):
-                assert int(ed["inexact"][k]) == flag_of(float(ed["w"][k])), "the device's inexact flag differs from its statement"
-                e = eps_of(float(ed["w"][k]), int(ed["inexact"][k]))
-                n_edges += 1
-                n_inexact += e > 0
-                if abs(Wref[k] - Wdev[k]) > e:
-                    bad_eps += 1
-                    if bad_eps <= 5:
-                        print("EPS TOO SMALL contig %d edge %d: w=%r dev %d ref %d eps %d" % (b0 + i, k, float(ed["w"][k]), Wdev[k], Wref[k], e))
+            n_edges += len(ed); n_flag += int(ed["inexact"].sum()); n_eps += int(((ed["inexact"] != 0) & (ed["err"] != 0)).sum())
+            viol = bounds_hold(ed, wdec)
+            bad_b += len(viol)
+            for v in viol[:3]:
+                print("BOUNDS VIOLATED contig %d edge %d: w=%r W*-W=%d bounds %s" % ((b0 + i,) + v))
             dist = ann.dist(i)
             path = [int(x) for x in ann.path(i)[0]]
-            why, ok = certify(nd, ed, dist, path)
+            why, ok = certify(nd, ed, dist, path, ties=gl.tie != 0)
+            assert ok == int(cert[i]), (b0 + i, why, int(cert[i]))
             p_dec = solve(nd, ed, wdec)
             same = p_dec == path
             n_cert += ok
@@ -171,8 +186,8 @@ def main():
                     print("CERTIFIED BUT DIFFERENT contig %d" % (b0 + i))
             else:
                 reasons.append((b0 + i, len(part[i]), int(gl.tie), why, same))
-    print("certify probe seed %d: %d contigs, %d certified (%d of them with ties), of those %d same / %d different Decimal path; eps violated on %d of %d edges (%d inexact); %.0f s"
-          % (seed, n_ok, n_cert, ties_cert, n_same, n_diff, bad_eps, n_edges, n_inexact, time.time() - t0))
+    print("certify probe seed %d: %d contigs, %d certified (%d of them with ties), of those %d same / %d different Decimal path; bounds violated on %d of %d edges (%d still flagged after k_refine, %d of them with eps > 0); %.0f s"
+          % (seed, n_ok, n_cert, ties_cert, n_same, n_diff, bad_b, n_edges, n_flag, n_eps, time.time() - t0))
     for r in reasons[:40]:
         print("  uncertified contig %d (L %d, tie flag %d): %s; Decimal path %s" % (r[0], r[1], r[2], r[3], "same" if r[4] else "DIFFERENT"))
 
