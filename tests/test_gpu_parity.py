@@ -53,8 +53,9 @@ def check_exact_distances(ann, i):
     assert not bad, "contig %d: %d of %d distances differ, first at node %d: %r vs %r" % (i, len(bad), len(want), bad[0], got[bad[0]], want[bad[0]])
 
 
-def check_contig(ann, i, seq, o, genes, status, params=None):
-    """All stage taps of contig i against the oracle result o."""
+def check_contig(ann, i, seq, o, genes, status, params=None, fp64_decides=True):
+    """All stage taps of contig i against the oracle result o.  fp64_decides=False: a contig whose path the fp64-level oracle cannot know
+    (the neartie fixtures): everything but path and genes."""
     if o["status"] < 0:
         assert status == o["status"]
         assert len(genes) == 0
@@ -106,6 +107,9 @@ def check_contig(ann, i, seq, o, genes, status, params=None):
         assert np.array_equal(gk[gi], ok[oi])
         np.testing.assert_allclose(ed["w"][gi], o["edge_weight"][oi], rtol=WTOL)
     p, dist = ann.path(i)
+    if not fp64_decides:
+        check_exact_distances(ann, i)
+        return
     assert np.array_equal(nd["refidx"][p] if len(p) else p, o["path"])
     if len(o["path"]):
         assert abs(dist - o["path_dist"]) <= abs(o["path_dist"]) * WTOL  # the oracle's weights come from the host libm
@@ -132,7 +136,7 @@ def test_golden_case(case, pa, oracle):
         if str(g["error"]) == "ValueError":
             assert status == -6 and o["status"] == -6  # "parallel edges are forbidden", graphs.py:74 (PHX_S_PARALLEL)
     else:
-        check_contig(ann, 0, seq, o, genes, status, kw)
+        check_contig(ann, 0, seq, o, genes, status, kw, fp64_decides=not case.startswith("neartie"))
         # the reference's own numbers (Decimal + exact-integer solver), tests/golden/*.npz
         assert np.array_equal(genes["left"], g["gene_left"])
         assert np.array_equal(genes["right"], g["gene_right"])
@@ -1102,7 +1106,7 @@ def test_certificate_kernel_equals_its_python_statement(pa):
                     assert cert[i] == 1
                     continue
                 ed = ann.edges(i)
-                n_flag[tight][0] += int(ed["inexact"].sum()); n_flag[tight][1] += len(ed)
+                n_flag[tight][0] += int(((ed["inexact"] != 0) & (ed["err"] != 0)).sum()); n_flag[tight][1] += len(ed)
                 if (b0 + i) % 6 == 0 or flags == ():
                     viol = certify_probe.bounds_hold(ed, dump.decimal_weights(ann, i, part[i])[2])
                     assert not viol, (flags, b0 + i, viol[:3])
@@ -1111,7 +1115,7 @@ def test_certificate_kernel_equals_its_python_statement(pa):
                 n_fail[tight] += 1 - ok
         ann.close()
     assert n_fail[False] == 0 and n_fail[True] >= 30, (n_fail, n_flag)
-    assert n_flag[False][0] * 200 < n_flag[False][1], n_flag  # with the product's bounds less than half a per cent of the edges stay flagged
+    assert n_flag[False][0] * 200 < n_flag[False][1], n_flag  # with the product's bounds less than half a per cent of the edges keep an eps > 0 (those beyond ~1e22)
     a = pa.Annotator(flags=("no_certify",))
     a.annotate(seqs[:3])
     assert (a.certified() == -1).all()
@@ -1172,6 +1176,42 @@ def test_contigs_without_a_graph_are_certified(pa):
     assert ann.certified().tolist() == [1, 1, 1] and ann.resolved == []
     assert [ann.globals(i).n_node for i in range(3)] == [2, 2, 2]
     ann.close()
+
+
+def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
+    """A constructed contig whose fp64-integer path and Decimal-integer path differ (tests/golden/make_neartie.py, generated through the
+    reference): the same 24 kb contig with two -s weights for gtg that are 5e-28 apart and between which the reference's path changes —
+    a 3.5e21 ORF decides.  A double reads both flags as the same number, so the device's first pass gives ONE path for both; the final
+    genes must be the reference's for both.  For the one it got wrong the certificate fails (k_refine knows the reference's integers,
+    the path is not optimal for them), the contig is solved again on the host in the reference's own arithmetic (phx_exact.inc), and the
+    result differs from what the device alone reported."""
+    from phanotate_amd import dump
+
+    n_changed = 0
+    raw_paths = []
+    for case in ("neartie_lo", "neartie_hi"):
+        g, name, seq = load_golden(case)
+        kw = golden_params(g)
+        ann = pa.Annotator(pa.make_params(**kw))
+        st, offs, genes = ann.annotate_flat([seq])
+        cert = int(ann.certified()[0])
+        assert st[0] == 0 and cert in (1, 2)
+        assert np.array_equal(genes["left"], g["gene_left"]) and np.array_equal(genes["right"], g["gene_right"]) and np.array_equal(genes["strand"], g["gene_strand"].astype(np.int32)), case
+        np.testing.assert_allclose(genes["score"], g["gene_score"], rtol=1e-6)
+        py = dump.python_resolve(ann, 0, seq, kw["start_codons"])  # decimal.Decimal itself + python ints
+        assert [(int(x["left"]), int(x["right"]), int(x["strand"])) for x in genes] == [t[:3] for t in py]
+        raw = ann.download_flat(exact=False)[2]
+        raw_paths.append([(int(x["left"]), int(x["right"])) for x in raw])
+        if raw.tobytes() != genes.tobytes():
+            n_changed += 1
+            assert cert == 2 and ann.globals(0).certified == 2
+            assert not np.array_equal(raw["left"], genes["left"]) or not np.array_equal(raw["right"], genes["right"])
+        # the whole C-ABI path (struct of pointers) delivers the same
+        (st2, g2), = ann.annotate([seq])
+        assert g2.tobytes() == genes.tobytes()
+        ann.close()
+    assert raw_paths[0] == raw_paths[1], "fp64 reads both weights as one number"
+    assert n_changed == 1, "the host re-solve must change exactly one of the two results"
 
 
 def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
