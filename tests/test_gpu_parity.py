@@ -1145,7 +1145,6 @@ def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, ora
     np.testing.assert_allclose(got[2]["score"], want[2]["score"], rtol=1e-12)
     raw = tight.download_flat(exact=False)  # what the device itself reported: the same here
     assert raw[2].tobytes() == want[2].tobytes() and tight.resolved == []
-    assert (tight.certified() != 2).all()
     again = tight.download_flat()           # and the guarantee is back on
     assert again[2].tobytes() == got[2].tobytes() and len(tight.resolved) >= 10
     for i in tight.resolved[:12]:
@@ -1195,7 +1194,7 @@ def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
         ann = pa.Annotator(pa.make_params(**kw))
         st, offs, genes = ann.annotate_flat([seq])
         cert = int(ann.certified()[0])
-        assert st[0] == 0 and cert in (1, 2)
+        assert st[0] == 0 and cert in (1, 2) and ann.globals(0).certified == cert
         assert np.array_equal(genes["left"], g["gene_left"]) and np.array_equal(genes["right"], g["gene_right"]) and np.array_equal(genes["strand"], g["gene_strand"].astype(np.int32)), case
         np.testing.assert_allclose(genes["score"], g["gene_score"], rtol=1e-6)
         py = dump.python_resolve(ann, 0, seq, kw["start_codons"])  # decimal.Decimal itself + python ints
@@ -1204,7 +1203,7 @@ def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
         raw_paths.append([(int(x["left"]), int(x["right"])) for x in raw])
         if raw.tobytes() != genes.tobytes():
             n_changed += 1
-            assert cert == 2 and ann.globals(0).certified == 2
+            assert cert == 2
             assert not np.array_equal(raw["left"], genes["left"]) or not np.array_equal(raw["right"], genes["right"])
         # the whole C-ABI path (struct of pointers) delivers the same
         (st2, g2), = ann.annotate([seq])
