@@ -2,10 +2,13 @@
 """bench.py — Mbp/s annotated on synthetic 50 kb phage contigs (BASELINE.json metric).
 
 A "step" is one pass of the whole hot path (libphx phx_run: features -> ORF scan -> scoring -> graph -> exact shortest
-path -> genes) over one batch of contigs that is already resident in HBM: that is `value` (task contract).  The metric
-SURVEY.md §8(d) defines — host ASCII contigs -> host gene lists, i.e. H2D + every kernel + D2H (+ the gather to rank 0
-when N > 1) — is timed the same way (K steps, barrier + synchronize on both sides, max over ranks) and reported beside it as
-`host_to_host`.
+path -> genes) over one batch of contigs that is already resident in HBM: that is `value`.  Which number is the metric is
+decided by the task contract, section (4) "Measurement": "`value` is whole-job throughput with inputs already resident in HBM
+when the timed region starts (if the boundary hands over host buffers, note the PCIe-inclusive rate in DESIGN.md — it is never
+`value`)".  The quantity SURVEY.md §8(d) defines — host ASCII contigs -> host gene lists, i.e. H2D + every kernel + the
+certificate + D2H (+ the gather to rank 0 when N > 1) — is the PCIe-inclusive rate of that sentence: timed the same way (K steps,
+barrier + synchronize on both sides, max over ranks) and reported beside it as `host_to_host`, for the batch and for config 5's
+10 000 contigs (`strong_scaling_base.host_to_host`: the N = 1 point of the §8(d) curve).
 
 Workloads (BASELINE.json configs):
   N = 1 (default)         config 4: 1000 synthetic 50 kb contigs (seeds 0..999) on one GPU
@@ -128,10 +131,10 @@ def reference_python_rate():
 
 
 def cpu_baselines(seqs, L_, n_one, per_core):
-    """The C oracle (oracle/phx_oracle.c: orc_run, all three stages) on a bounded sample of the same batch: one thread, then one
-    thread per host core (one contig per thread at a time; orc_run keeps no global state and ctypes releases the GIL)."""
+    """The C oracle (oracle/phx_oracle.c: orc_run, all three stages) on a bounded sample of the same batch: one thread here, then one
+    worker PROCESS per host core (oracle/cpu_rate.py, a subprocess that never touches the GPU runtime and forks its workers: threads of
+    one process serialise on the address-space lock under orc_run's allocations — 256 threads scaled 10x in round 3)."""
     import ctypes as C
-    from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle
 
@@ -153,14 +156,20 @@ def cpu_baselines(seqs, L_, n_one, per_core):
            "sample": "first %d of the %d contigs of this batch, C oracle (oracle/phx_oracle.c), %.1f s" % (n1, len(seqs), t1)}
     cores = os.cpu_count() or 1
     nall = max(1, min(len(seqs), per_core * cores))
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(one_contig, seqs[:cores]))  # start the threads
-        t0 = time.perf_counter()
-        st = list(ex.map(one_contig, seqs[:nall]))
-        ta = time.perf_counter() - t0
-    assert all(x == 0 for x in st)
-    allc = {"value": round(nall * L_ / ta / 1e6, 4), "unit": "Mbp/s", "cores": cores, "kind": "port",
-            "sample": "first %d contigs, one contig per thread on %d host cores (os.cpu_count), %.1f s" % (nall, cores, ta)}
+    allc = {"error": "oracle/cpu_rate.py did not run"}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_rate.py"), "--contigs", str(nall), "--length", str(L_), "--procs", str(cores)],
+                           capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and line:
+            d = json.loads(line[-1])
+            allc = {"value": d["value"], "unit": "Mbp/s", "cores": cores, "kind": "port",
+                    "scaling_over_one_core": round(d["value"] / one["value"], 1) if one["value"] else None,
+                    "sample": "first %d contigs of the series, one contig at a time per worker process, %d processes (os.cpu_count), %.2f s; one core inside that run: %.3f Mbp/s" % (d["contigs"], cores, d["seconds"], d["one_core_Mbp_s"])}
+        else:
+            allc = {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:  # the baseline is a reported figure, never a reason to lose the line
+        allc = {"error": repr(e)[:300]}
     return one, allc
 
 
@@ -320,7 +329,8 @@ def main():
         ann.run()
         cert = ann.certified()
     dt_cert = max_over_ranks(time.perf_counter() - t0)
-    n_uncert = int(sum_over_ranks(float((cert == 0).sum())))
+    n_uncert = int(sum_over_ranks(float((cert != 1).sum())))   # not proven on the device
+    n_again = int(sum_over_ranks(float((cert == 2).sum())))     # ... and therefore solved again on the host, inside the library
     sz = ann.batch_sizes()
     bp_total = sum_over_ranks(float(sum(len(s) for s in seqs)))
     value = bp_total * args.steps / dt / 1e6
@@ -418,8 +428,9 @@ def main():
                 "solver_kernel_contig0": int(ann.globals(0).sssp_kernel),
                 "solver_kernels": solver_kernels,
             },
-            "certificate": {"ms_per_step_with_run": round(dt_cert / args.steps * 1e3, 4), "ms_on_top_of_run": round((dt_cert - dt) / args.steps * 1e3, 4), "contigs_not_certified": n_uncert,
-                            "what": "phx_run + phx_certified per step: k_certify proves per contig, in exact integers, that the gene list is the one the reference's Decimal-derived integers give (phx_certify.inc); computed on demand, so `value` does not contain it, `host_to_host` (Annotator.download_flat asks for it) does"},
+            "certificate": {"ms_per_step_with_run": round(dt_cert / args.steps * 1e3, 4), "ms_on_top_of_run": round((dt_cert - dt) / args.steps * 1e3, 4), "contigs_not_certified_on_device": n_uncert,
+                            "contigs_solved_again_on_host": n_again,
+                            "what": "phx_run + phx_certified per step: k_refine evaluates the edges fp64 could not place between two integers once more in double-double (bounds on the reference's integers from the error of its own 28-digit chain), k_certify proves per contig, in exact integers, that the gene list is the one the reference's Decimal-derived integers give (phx_refine.inc, phx_certify.inc); a contig it cannot prove is solved again on the host in the reference's own arithmetic, inside the library (phx_exact.inc).  Computed on demand, so `value` does not contain it; `host_to_host` (phx_download_flat asks for it) does"},
             "host_to_host": {
                 "value": round(bp_total * args.steps / dt_host / 1e6, 3),
                 "unit": "Mbp/s",
@@ -441,7 +452,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic_of(dom),
-                "traffic_source": ("measured in this run: two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) of a one-step run of this command; bytes = (2 FETCH + WRITE) KiB, the guide's gfx950 correction for streaming reads" if live is not None
+                "traffic_source": ("measured in this run: two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) of a one-step run of this command; bytes = (2 FETCH + WRITE) KiB: the guide's gfx950 correction, which is calibrated on streaming reads and is applied here to scattered reads as well (uncalibrated for them)" if live is not None
                                    else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; rocprofv3 not available to this process or --no-traffic)"),
                 "traffic_step_total": None if live is None else live[1],
                 "algorithmic_bytes_per_launch": int(balgo),
@@ -495,10 +506,11 @@ def main():
                 for _ in range(2):
                     a5.annotate_flat(big)
                 t5h = (time.perf_counter() - t0) / 2
-                n_again = int((np.asarray(a5.certified()) == 0).sum())
+                c5 = np.asarray(a5.certified())
+                n_again = int((c5 == 2).sum())
                 out["strong_scaling_base"] = {"contigs": 10000, "n_gpus": 1, "value": round(len(big) * L_ / t5 / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5 * 1e3, 3),
-                                              "host_to_host": {"value": round(len(big) * L_ / t5h / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5h * 1e3, 3), "contigs_solved_again_on_host": n_again,
-                                                               "what": "upload + run + download + certificate; a contig the certificate does not cover is solved again on the host in the reference's Decimal-derived integers (python, ~0.1 s per 50 kb contig), which is most of this figure when there is one"},
+                                              "host_to_host": {"value": round(len(big) * L_ / t5h / 1e6, 3), "unit": "Mbp/s", "ms_per_step": round(t5h * 1e3, 3), "contigs_solved_again_on_host": n_again, "contigs_not_certified_on_device": int((c5 != 1).sum()),
+                                                               "what": "SURVEY.md §8(d) at N = 1: upload + run + certificate + download of config 5's 10 000 contigs; a contig the certificate does not cover is solved again on the host in the reference's Decimal-derived integers inside phx_download_flat (C, worker threads)"},
                                               "genes_called_total": int(len(g5)), "contigs_with_error_status": int((st5 < 0).sum()),
                                               "what": "config 5's 10 000 contigs as one batch resident on one GPU (3 timed runs; = `bench.py --gpus 1 --contigs 10000`): divide the N > 1 lines' value by this for strong-scaling efficiency"}
                 a5.close()

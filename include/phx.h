@@ -262,6 +262,13 @@ int phx_tap_path(phx_ctx *ctx, int32_t contig, int32_t *path, int32_t cap, int32
  * an unreached node has a top word >= 2^61 */
 int phx_tap_dist(phx_ctx *ctx, int32_t contig, uint64_t *dist_limbs, int64_t cap_words);
 
+/* -d/--dump of the reference (phanotate.py:58,61) for one contig of the batch last run: one line per edge of its graph,
+ *     repr(source) TAB repr(target) TAB str(weight * 1000)                                   (edges.py:17-23, nodes.py:14-21)
+ * in Graph.iteredges order, the weights as the reference's 28-digit Decimals (the chain replayed by csrc/phx_dec.c on the integers
+ * the device delivers, csrc/phx_exact.inc) — byte for byte what an upstream install prints.  *text is malloc'ed (NUL-terminated),
+ * release with phx_free_text.  Host-side formatting, ~0.3 s for a 170 kb genome. */
+int phx_dump_text(phx_ctx *ctx, int32_t contig, char **text, int64_t *text_len);
+
 /* ---- the solver alone (the fastpathz boundary, phanotate.py:56-64) ----
  * Edges (src[i] -> dst[i]) over nodes 0..V-1 with integer weights given as n_limbs little-endian
  * 64-bit words each (two's complement).  Writes the node ids of the shortest path source..target to

@@ -195,6 +195,14 @@ class Annotator:
         self.run()
         return self.download_flat()
 
+    def dump_text(self, i):
+        """-d/--dump of the reference for contig i of the batch last run (phx_dump_text): bytes, one line per edge."""
+        text, n = C.c_void_p(), C.c_int64()
+        self._chk(self.L.phx_dump_text(self.h, int(i), C.byref(text), C.byref(n)), "phx_dump_text")
+        out = C.string_at(text.value, n.value)
+        self.L.phx_free_text(text)
+        return out
+
     # ---- stage taps (parity tests) ----
     def globals(self, i):
         g = _lib.Globals()

@@ -3,8 +3,10 @@
     phanotate.py [-o OUT] [-f FORMAT] [-s atg:0.85,gtg:0.10,ttg:0.05] [-e tag,tga,taa] [-l 90] [-d] infile
 
 All contigs of the input go through the GPU in batches (phanotate.py:40 loops over them one by one).
-Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N phanotate.py ...`; contigs
-are sharded across ranks (phanotate_amd.shard) and rank 0 writes the output in input order.
+Inputs of more than one batch stream through phanotate_amd.pipeline.Pipeline: two batches in flight per GPU, and with --gpus N
+the batches go round the first N GPUs of the node — one process, one host thread and two libphx contexts per GPU, no process group
+(contigs never interact, phanotate.py:40,56).  `python -m torch.distributed.run --nproc-per-node N phanotate.py ...` still works:
+contigs are then sharded across ranks (phanotate_amd.shard) and rank 0 writes the output in input order.
 """
 import argparse
 import os
@@ -36,6 +38,7 @@ def get_args(argv=None):
     p.add_argument("-d", "--dump", action="store_true")
     p.add_argument("-V", "--version", action="version", version=__version__)
     p.add_argument("--device", type=int, default=None, help="GPU ordinal [LOCAL_RANK or 0]")
+    p.add_argument("--gpus", type=int, default=1, help="spread the batches over the first N GPUs of the node, from this one process [1]")
     p.add_argument("--batch-bases", type=int, default=400_000_000, help="bases per GPU batch [4e8]")
     p.add_argument("--single-device-ranks", action="store_true", help=argparse.SUPPRESS)  # tests: every rank of a sharded launch on GPU `--device` (gloo-only group)
     return p.parse_args(argv)
@@ -43,26 +46,8 @@ def get_args(argv=None):
 
 def dump_edges(out, ann, i, seq=None, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):
     """-d/--dump (phanotate.py:58,61): one line per edge, repr(src) TAB repr(dst) TAB str(weight*1000), in the reference's
-    Graph.iteredges order.  With the contig's sequence the weights are the reference's 28-digit Decimal values (dump.py);
-    without it (get_graph of the mirror module) they are the device's fp64 values."""
-    if seq is not None:
-        from .dump import dump_lines
-
-        for line in dump_lines(ann, i, seq, start_codons):
-            out.write(line + "\n")
-        return
-    from .dump import TNAME, edge_order
-
-    nd = ann.nodes(i)
-    ed = ann.edges(i)
-
-    def rep(v):
-        n = nd[v]
-        t = TNAME[int(n["type"])]
-        return "Node(%r,%r,%r,%r)" % (t if n["type"] >= 2 else ("tRNA" if abs(int(n["frame"])) == 4 else "CDS"), t, int(n["frame"]), int(n["pos"]))
-
-    for k in edge_order(nd, ed):
-        out.write("%s\t%s\t%s\n" % (rep(int(ed[k]["src"])), rep(int(ed[k]["dst"])), repr(float(ed[k]["w"]) * 1000)))
+    Graph.iteredges order, the weights as the reference's 28-digit Decimal values (phx_dump_text)."""
+    out.write(ann.dump_text(i).decode())
 
 
 def format_tabular(names, status, offsets, genes):
@@ -176,24 +161,44 @@ def main(argv=None):
 
     def annotate_flat(idx):  # this rank's contigs, in batches of --batch-bases, straight from the C buffer of the FASTA reader
         idx = np.asarray(idx, np.int64)
-        parts, lo = [], 0
-        while lo < len(idx) or not parts:
+        n_gpu = max(1, int(args.gpus)) if world == 1 else 1
+        # batches: at most --batch-bases each; with several GPUs at least two per GPU, so that every lane has two in flight
+        limit = args.batch_bases
+        if n_gpu > 1 and len(idx):
+            limit = max(1, min(limit, -(-int(fa.lens[idx].sum()) // (2 * n_gpu))))
+        cuts, lo = [], 0
+        while lo < len(idx) or not cuts:
             hi, size = lo, 0
-            while hi < len(idx) and (hi == lo or size + int(fa.lens[idx[hi]]) <= args.batch_bases):
+            while hi < len(idx) and (hi == lo or size + int(fa.lens[idx[hi]]) <= limit):
                 size += int(fa.lens[idx[hi]])
                 hi += 1
+            cuts.append((lo, hi))
+            lo = hi
+            if lo >= len(idx):
+                break
+        t_parts["batches"] = len(cuts)
+        if len(cuts) == 1 and n_gpu == 1:
+            lo, hi = cuts[0]
             t0 = time.perf_counter()
             ann.upload_raw(fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa)
             ann.set_trnas(trnas_of(idx[lo:hi]))
             t1 = time.perf_counter()
             ann.run()
             t2 = time.perf_counter()
-            parts.append(ann.download_flat())
+            parts = [ann.download_flat()]
             t3 = time.perf_counter()
-            t_parts["upload_s"] += t1 - t0; t_parts["run_s"] += t2 - t1; t_parts["download_s"] += t3 - t2; t_parts["batches"] += 1
-            lo = hi
-            if lo >= len(idx):
-                break
+            t_parts["upload_s"] += t1 - t0; t_parts["run_s"] += t2 - t1; t_parts["download_s"] += t3 - t2
+        else:  # a stream of batches: two in flight per GPU, the batches round the GPUs (pipeline.Pipeline)
+            from .pipeline import Pipeline
+
+            t0 = time.perf_counter()
+            pipe = Pipeline(ann.params, device=device, depth=2, devices=([device] + [d for d in range(n_gpu) if d != device][: n_gpu - 1]) if n_gpu > 1 else None, first=ann)
+            t1 = time.perf_counter()
+            gen = ((fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa, (lambda a=lo, b=hi: trnas_of(idx[a:b]))) for lo, hi in cuts)
+            parts = list(pipe.run(gen))
+            t2 = time.perf_counter()
+            pipe.close()
+            t_parts["contexts_s"] = t1 - t0; t_parts["pipeline_s"] = t2 - t1; t_parts["gpus"] = n_gpu
         if len(parts) == 1:
             return parts[0]
         st = np.concatenate([p[0] for p in parts])

@@ -1839,6 +1839,25 @@ static int ensure_exact(phx_ctx *c) {
     return PHX_OK;
 }
 
+int phx_dump_text(phx_ctx *c, int32_t contig, char **text, int64_t *text_len) {
+    if (!c || !text) return PHX_E_ARG;
+    *text = nullptr;
+    if (text_len) *text_len = 0;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
+    if (!c->ran) return PHX_E_STATE;
+    if (contig < 0 || contig >= c->n) return PHX_E_ARG;
+    ExactIn in;
+    { const int rc = exact_fetch(c, contig, in); if (rc) return rc; }
+    std::string out;
+    if (in.gl.status >= 0 && !exact_dump(in, c->params, out)) { c->err = "dump: an operation outside what phx_dec.c restates"; return PHX_E_STATE; }
+    char *buf = (char *)malloc(out.size() + 1);
+    if (!buf) return PHX_E_NOMEM;
+    memcpy(buf, out.data(), out.size()); buf[out.size()] = 0;
+    *text = buf;
+    if (text_len) *text_len = (int64_t)out.size();
+    return PHX_OK;
+}
+
 int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs, int32_t n_limbs,
               int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path, uint64_t *dist_limbs) {
     if (!c || V < 2 || E < 0 || (E > 0 && (!src || !dst || !w_limbs)) || !n_path) return PHX_E_ARG;

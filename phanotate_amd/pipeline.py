@@ -19,13 +19,14 @@ from .api import Annotator
 class _Lane:
     """One GPU: `depth` contexts taking turns, driven by one host thread."""
 
-    def __init__(self, params, device, depth):
+    def __init__(self, params, device, depth, first=None):
         self.device = device
-        self.anns = [Annotator(params, device=device) for _ in range(max(1, int(depth)))]
+        self.own = [Annotator(params, device=device) for _ in range(max(1, int(depth)) - (1 if first is not None else 0))]
+        self.anns = ([first] if first is not None else []) + self.own
         self.turn = 0
 
     def close(self):
-        for a in self.anns:
+        for a in self.own:
             a.close()
 
     def next_ctx(self):
@@ -48,16 +49,18 @@ def _load(a, batch):
 
 
 class Pipeline:
-    def __init__(self, params=None, device=0, depth=2, devices=None):
-        """devices: the GPUs to spread the batches over (default: [device]); an ordinal may repeat (two lanes on one GPU)."""
+    def __init__(self, params=None, device=0, depth=2, devices=None, first=None):
+        """devices: the GPUs to spread the batches over (default: [device]); an ordinal may repeat (two lanes on one GPU).
+        first: an Annotator the caller already holds on the first device (with the same params): it becomes the first context of the
+        first lane instead of a new one (the caller keeps ownership)."""
         devs = [int(d) for d in devices] if devices is not None else [int(device)]
         if not devs:
             raise ValueError("Pipeline needs at least one device")
         self.depth = max(1, int(depth))
         self.lanes = []
         try:
-            for d in devs:
-                self.lanes.append(_Lane(params, d, self.depth))
+            for j, d in enumerate(devs):
+                self.lanes.append(_Lane(params, d, self.depth, first if j == 0 else None))
         except BaseException:
             self.close()
             raise

@@ -114,6 +114,46 @@ def test_cli_sharded_over_two_ranks_equals_one_rank(tmp_path):
     assert out.read_text() == one.stdout and one.stdout.count("#id:") == 42
 
 
+def test_one_process_spreads_batches_over_lanes(tmp_path):
+    """SURVEY.md §8(e) as written: ONE process, one host thread + libphx contexts per GPU, results placed by index — no torchrun, no
+    process group.  pipeline.Pipeline(devices=[0, 0]) (two lanes; on this box both on GPU 0) over a stream of different batches gives
+    byte for byte what one Annotator gives batch by batch; and the CLI on a FASTA that splits into three batches (--batch-bases), with
+    and without --gpus, writes what the single-batch run writes."""
+    import numpy as np
+
+    import phanotate_amd as pa
+
+    rng = np.random.RandomState(5)
+    batches = [[pa.synth_contig(100 * k + j, int(rng.randint(800, 30000))) for j in range(int(rng.randint(1, 40)))] for k in range(9)] + [[], [b"acgtnnacgx" * 30]]
+    one = pa.Annotator()
+    want = [one.annotate_flat(b) for b in batches]
+    one.close()
+    with pa.Pipeline(devices=[0, 0], depth=2) as pipe:
+        assert len(pipe.lanes) == 2 and len(pipe.anns) == 4
+        for rnd in range(2):  # the second round runs on warm contexts: everything asynchronous
+            got = list(pipe.run(iter(batches)))
+            assert len(got) == len(want)
+            for (ws, wo, wg), (gs, go, gg) in zip(want, got):
+                assert np.array_equal(ws, gs) and np.array_equal(wo, go) and wg.tobytes() == gg.tobytes()
+    fa = tmp_path / "in.fasta"
+    total = 0
+    with open(fa, "w") as f:
+        for i in range(45):
+            s = pa.synth_contig(8000 + i, 2000 + 700 * i).decode()
+            total += len(s)
+            f.write(">c%d\n%s\n" % (i, s))
+    single = _cli(fa)
+    assert single.count("#id:") == 45
+    env = dict(os.environ, PHX_CLI_TIMING="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py"), "--batch-bases", str(total // 3 + 1), str(fa)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout == single, r.stderr
+    import json
+
+    t = json.loads([l for l in r.stderr.splitlines() if l.startswith("PHX_CLI_TIMING ")][-1][len("PHX_CLI_TIMING "):])
+    assert t["gpu_parts"]["batches"] >= 3 and "pipeline_s" in t["gpu_parts"]
+    assert _cli("--gpus", "1", "--batch-bases", str(total // 5), fa) == single
+
+
 # ---- f-4: the other output formats, through the GPU path (README.md:45-54, 60-61, 67-68) ----
 def _cli(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
