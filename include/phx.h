@@ -302,6 +302,11 @@ int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t
  * it), "float" (Decimal(float(a))), "repr" (repr(float(a))), "trunc1000" (int(a * 1000) as 18 hex words), "dd" (a as a double-double).
  * The result text goes to out; returns its length or a negative error. */
 int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *out, int cap);
+/* The double-double arithmetic of k_refine (csrc/phx_dd.h; it compiles for the host too), for the tests: op = "add" "sub" "mul" "div"
+ * "exp" "log" on (ah + al) and (bh + bl), "repr" = the decimal value Decimal(repr(ah)) holds; phx_dd_shortest: the digits and decimal
+ * exponent of repr(x) for 1e-10 <= x <= 1e10 (returns the number of digits, 0 outside that range). */
+int phx_dd_eval(const char *op, double ah, double al, double bh, double bl, double *rh, double *rl);
+int phx_dd_shortest(double x, uint64_t *digits, int32_t *exp10);
 
 /* ---- host I/O of the CLI (no device needed; phx_host.c) ----
  * Files and texts beyond a few MB are parsed / formatted by worker threads (one per online core, at most 16; the environment

@@ -47,7 +47,18 @@ def main():
     ap.add_argument("--length", type=int, default=50000)
     ap.add_argument("--procs", type=int, default=0)
     args = ap.parse_args()
-    procs = args.procs or (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None  # the container's CPU allowance (cgroup v2 cpu.max, v1 cfs quota): worker processes beyond it only take turns
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) if q > 0 else None
+        except Exception:
+            pass
+    procs = args.procs or max(1, min(visible, int(quota + 0.5) if quota else visible))
     so = C.CDLL(os.path.join(ROOT, "phanotate_amd", "libphx.so"))
     so.phx_synth_contig.argtypes = [C.c_uint64, C.c_int64, C.c_char_p]
     for s in range(args.contigs):
@@ -69,7 +80,7 @@ def main():
     rate = args.contigs * args.length / dt / 1e6
     one = args.length / t_one / 1e6
     print(json.dumps({"value": round(rate, 4), "unit": "Mbp/s", "cores": procs, "kind": "port", "seconds": round(dt, 3), "contigs": args.contigs,
-                      "one_core_Mbp_s": round(one, 4), "scaling_over_one_core": round(rate / one, 2)}))
+                      "one_core_Mbp_s": round(one, 4), "scaling_over_one_core": round(rate / one, 2), "cpus_visible": visible, "cgroup_cpu_quota": quota}))
 
 
 if __name__ == "__main__":

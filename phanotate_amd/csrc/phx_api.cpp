@@ -1839,6 +1839,33 @@ static int ensure_exact(phx_ctx *c) {
     return PHX_OK;
 }
 
+} // extern "C"
+#include "phx_dd.h"
+extern "C" {
+// test hooks for the double-double arithmetic of k_refine (phx_dd.h compiles for the host as well): tests/test_dec.py
+int phx_dd_eval(const char *op, double ah, double al, double bh, double bl, double *rh, double *rl) {
+    if (!op || !rh || !rl) return PHX_E_ARG;
+    const dd_t a = dd_make(ah, al), b = dd_make(bh, bl);
+    dd_t r = dd_make(0, 0);
+    if (!strcmp(op, "add")) r = dd_add(a, b);
+    else if (!strcmp(op, "sub")) r = dd_sub(a, b);
+    else if (!strcmp(op, "mul")) r = dd_mul(a, b);
+    else if (!strcmp(op, "div")) r = dd_div(a, b);
+    else if (!strcmp(op, "exp")) r = dd_exp(a);
+    else if (!strcmp(op, "log")) r = dd_log(a);
+    else if (!strcmp(op, "repr")) { int ok; r = dd_repr_value(ah, &ok); if (!ok) return PHX_E_ARG; }
+    else return PHX_E_ARG;
+    *rh = r.hi; *rl = r.lo;
+    return PHX_OK;
+}
+int phx_dd_shortest(double x, uint64_t *digits, int32_t *exp10) {
+    if (!digits || !exp10) return PHX_E_ARG;
+    int e = 0;
+    const int nd = dd_shortest(x, digits, &e);
+    *exp10 = e;
+    return nd;
+}
+
 int phx_dump_text(phx_ctx *c, int32_t contig, char **text, int64_t *text_len) {
     if (!c || !text) return PHX_E_ARG;
     *text = nullptr;

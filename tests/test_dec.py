@@ -126,3 +126,56 @@ def _defaults_via_flags(L):
     p = _lib.Params()
     assert L.phx_params_from_flags(b"atg:0.85,gtg:0.10,ttg:0.05", b"tag,tga,taa", 90, C.byref(p)) == 0
     return p
+
+
+def test_double_double_of_k_refine_against_60_digit_decimals():
+    """csrc/phx_dd.h (k_refine's arithmetic; the same header compiles for the host): + - * / to 2^-104, exp to (1 + |x|) 2^-104 relative
+    over the exponent range of the weights, ln(1 - p) to 2^-103 absolute, and repr(double) — the shortest digits that read back, the
+    text Decimal(str(weight_rbs)) is built from (orfs.py:126) — identical to Python's on 100 000 doubles."""
+    import math
+
+    L = _lib.lib()
+
+    def ev(op, a, b=(0.0, 0.0)):
+        rh, rl = C.c_double(), C.c_double()
+        assert L.phx_dd_eval(op.encode(), a[0], a[1], b[0], b[1], C.byref(rh), C.byref(rl)) == 0
+        return D(rh.value) + D(rl.value)
+
+    def todd(x):
+        h = float(x)
+        return (h, float(x - D(h)))
+
+    rnd = random.Random(6)
+    with localcontext() as ctx:
+        ctx.prec = 70
+        worst = {}
+        for _ in range(4000):
+            a = D(rnd.uniform(-10, 10)) * D(10) ** rnd.randint(-5, 5) + D(rnd.random()) * D(10) ** -20
+            b = D(rnd.uniform(-10, 10)) * D(10) ** rnd.randint(-5, 5) + D(rnd.random()) * D(10) ** -21
+            da, db = todd(a), todd(b)
+            A, B = D(da[0]) + D(da[1]), D(db[0]) + D(db[1])
+            for op, ref in (("add", A + B), ("sub", A - B), ("mul", A * B), ("div", A / B)):
+                worst[op] = max(worst.get(op, 0), abs((ev(op, da, db) - ref) / ref))
+            x = D(rnd.uniform(-2, 690)) + D(rnd.random()) * D(10) ** -18
+            dx = todd(x)
+            X = D(dx[0]) + D(dx[1])
+            worst["exp"] = max(worst.get("exp", 0), abs((ev("exp", dx) - X.exp()) / X.exp()) / (1 + abs(X)))
+            p = D(rnd.uniform(1e-9, 0.149))
+            db1 = todd(D(1) - p)
+            B1 = D(db1[0]) + D(db1[1])
+            worst["log"] = max(worst.get("log", 0), abs(ev("log", db1) - B1.ln()))
+        for op in ("add", "sub", "mul", "div", "exp"):
+            assert worst[op] < D(2) ** -104, (op, worst[op])
+        assert worst["log"] < D(2) ** -103, worst["log"]
+        bad = 0
+        for _ in range(100000):
+            x = rnd.choice([rnd.random(), rnd.uniform(0, 1e3), 10.0 ** rnd.uniform(-10, 10), (1 + rnd.randint(0, 5000)) / (28 + rnd.randint(1, 5000)) / ((1 + rnd.randint(0, 100000)) / (28 + rnd.randint(50000, 100000))),
+                            2.0 ** rnd.randint(-30, 30), float(rnd.randint(1, 10 ** rnd.randint(1, 10)))])
+            if not (1e-10 <= x <= 1e10):
+                continue
+            dg, e = C.c_uint64(), C.c_int32()
+            nd = L.phx_dd_shortest(x, C.byref(dg), C.byref(e))
+            ref = D(repr(x))
+            assert nd > 0 and D(dg.value) * D(10) ** e.value == ref and len(str(dg.value)) == nd, (repr(x), dg.value, e.value)
+            assert abs((ev("repr", (x, 0.0)) - ref) / ref) < D(2) ** -102
+        assert L.phx_dd_shortest(1e-11, C.byref(dg), C.byref(e)) == 0 and L.phx_dd_shortest(1e11, C.byref(dg), C.byref(e)) == 0
