@@ -278,13 +278,14 @@ int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int3
               uint64_t *dist_limbs);
 
 /* ---- measurement ---- */
-#define PHX_N_STAGES 13
+#define PHX_N_STAGES 14
 /* When on, every kernel launch of phx_run is bracketed by hipEvents on the ctx stream. */
 int phx_set_profiling(phx_ctx *ctx, int on);
 /* The same for a subset of the stages (bit k = stage k; 0 switches profiling off): two events per run instead of two per stage. */
 int phx_set_profiling_stages(phx_ctx *ctx, uint32_t stage_mask);
 /* ms[k] = accumulated GPU time of stage k since the last reset; names via phx_stage_name(k).  (Stage 10 was "edge_weights" and keeps its
-   index and now times k_certify: the overlap weights are evaluated inside the edge fill.) */
+   index and now times k_refine + k_certify: the overlap weights are evaluated inside the edge fill.  Stage 13, "wave_plan", runs on a side
+   stream BESIDE stage 8, "edges_fill": it is in the table, not in the sum of the main stream's stages.) */
 int phx_get_stage_ms(phx_ctx *ctx, float *ms /* [PHX_N_STAGES] */, int32_t *launches /* [PHX_N_STAGES] */, int reset);
 const char *phx_stage_name(int k);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */

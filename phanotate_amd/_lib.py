@@ -7,7 +7,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libphx.so")
 MAXC = 16
-N_STAGES = 13
+N_STAGES = 14
 
 
 class Params(C.Structure):

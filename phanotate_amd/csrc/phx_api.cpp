@@ -28,8 +28,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_CERTIFY, ST_COPY, ST_INORDER };
-const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "certify", "copies", "inorder"};
+enum Stage { ST_MEMSET = 0, ST_FEATURES, ST_ORF_COUNT, ST_ORF_EMIT, ST_ORF_STATS, ST_SCORE, ST_NODES, ST_EDGE_COUNT, ST_EDGE_FILL, ST_SSSP, ST_CERTIFY, ST_COPY, ST_INORDER, ST_WAVE_PLAN };
+const char *kStageName[PHX_N_STAGES] = {"memset", "features", "orf_count", "orf_emit", "orf_stats", "score", "nodes", "edges_count", "edges_fill", "sssp", "certify", "copies", "inorder", "wave_plan"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -316,13 +316,14 @@ hipEvent_t get_event(phx_ctx *c) {
     return e;
 }
 struct StageTimer {
-    phx_ctx *c; int st; bool on = false; hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(phx_ctx *c_, int st_) : c(c_), st(st_) {
+    phx_ctx *c; int st; bool on = false; hipEvent_t a = nullptr, b = nullptr; hipStream_t str = nullptr;
+    StageTimer(phx_ctx *c_, int st_, hipStream_t on_stream = nullptr) : c(c_), st(st_) { // on_stream: a side stream's kernels (k_wave_plan beside the edge fill)
         on = c->prof && ((c->prof_mask >> st_) & 1u);
-        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        str = on_stream ? on_stream : c->stream;
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, str); }
     }
     ~StageTimer() {
-        if (on) { (void)hipEventRecord(b, c->stream); c->pending.push_back({st, {a, b}}); }
+        if (on) { (void)hipEventRecord(b, str); c->pending.push_back({st, {a, b}}); }
     }
 };
 void collect_timers(phx_ctx *c) {
@@ -1036,8 +1037,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
     HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
-    phxk_wave_plan(&b, ((mask >> 6) & 1) | (((mask >> 10) & 1) << 1), c->aux[3]); // bits 4*1+2, 4*2+2: 256- / 512-bit contigs for the wavefront kernel
-    if (b.sord) phxk_sssp_order(&b, c->aux[3]);
+    {
+        StageTimer t(c, ST_WAVE_PLAN, c->aux[3]); // (on the side stream: runs beside "edges_fill", not in the sum of the main stream's stages)
+        phxk_wave_plan(&b, ((mask >> 6) & 1) | (((mask >> 10) & 1) << 1), c->aux[3]); // bits 4*1+2, 4*2+2: 256- / 512-bit contigs for the wavefront kernel
+        if (b.sord) phxk_sssp_order(&b, c->aux[3]);
+    }
     HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
     {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)

@@ -136,7 +136,13 @@ def test_golden_case(case, pa, oracle):
         if str(g["error"]) == "ValueError":
             assert status == -6 and o["status"] == -6  # "parallel edges are forbidden", graphs.py:74 (PHX_S_PARALLEL)
     else:
-        check_contig(ann, 0, seq, o, genes, status, kw, fp64_decides=not case.startswith("neartie"))
+        if case == "edge_wide":  # 431-bit path sums: the oracle stops at 256 bits; the device's distances against python ints, the path against the fixture
+            assert o["status"] == -7 and status == 0 and ann.globals(0).n_limbs == 8
+            check_exact_distances(ann, 0)
+            nd = ann.nodes(0)
+            assert np.array_equal(nd["refidx"][ann.path(0)[0]], g["path"]) and ann.path(0)[1] == int(str(g["path_dist"]))
+        else:
+            check_contig(ann, 0, seq, o, genes, status, kw, fp64_decides=not case.startswith("neartie"))
         # the reference's own numbers (Decimal + exact-integer solver), tests/golden/*.npz
         assert np.array_equal(genes["left"], g["gene_left"])
         assert np.array_equal(genes["right"], g["gene_right"])
@@ -1212,6 +1218,24 @@ def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
         ann.close()
     assert raw_paths[0] == raw_paths[1], "fp64 reads both weights as one number"
     assert n_changed == 1, "the host re-solve must change exactly one of the two results"
+
+
+def test_path_sums_beyond_1088_bits_are_reported_not_computed(pa):
+    """The reference's solver has no width limit (GMP, CHANGELOG.md:11-13); libphx stops at 1088-bit integers: a contig that needs more
+    (an open reading frame of 24 000 codons without a stop) gets PHX_S_OVERFLOW (-7) and no genes, the rest of the batch is not touched."""
+    rng = np.random.RandomState(12)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    body = "".join(sense[i] for i in rng.randint(0, len(sense), 24000))
+    huge = pa.synth_contig(320, 2000).decode() + "atg" + body + "taa" + pa.synth_contig(321, 2000).decode()
+    other = [pa.synth_contig(322 + k, 9000) for k in range(3)]
+    ann = pa.Annotator()
+    want = ann.annotate_flat(other)
+    st, offs, genes = ann.annotate_flat([other[0], huge, other[1], other[2]])
+    assert st.tolist() == [0, -7, 0, 0] and offs[2] == offs[1]
+    keep = np.concatenate([genes[offs[0]:offs[1]], genes[offs[2]:]])
+    assert keep.tobytes() == want[2].tobytes()
+    assert ann.certified().tolist() == [1, 1, 1, 1]
+    ann.close()
 
 
 def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
