@@ -181,7 +181,7 @@ def test_mixed_batch_equals_single_contig_runs(pa, oracle):
         g, name, seq = load_golden(c)
         if golden_trnas(g) is not None:
             continue
-        if golden_params(g) == dict(start_codons=str(load_golden("phiX174")[0]["params_start"]), stop_codons="tag,tga,taa", minlen=90):
+        if golden_params(g) == dict(start_codons=str(load_golden("phiX174")[0]["params_start"]), stop_codons="tag,tga,taa", minlen=90) and c != "edge_wide":  # (431-bit path sums: beyond the oracle, see test_golden_case)
             items.append((c, seq))
     assert len(items) >= 20
     seqs = [s for _, s in items] + ["", "acg"]  # plus an empty and a 3-base contig
