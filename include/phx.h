@@ -228,6 +228,20 @@ int phx_download(phx_ctx *ctx, phx_result *out);  /* D2H of the gene lists, [n] 
  * genes == NULL only offsets, status and total are filled (size query); cap = number of phx_gene records genes can take. */
 int phx_download_flat(phx_ctx *ctx, phx_gene *genes, int64_t cap, int64_t *offsets /* [n+1] */, int32_t *status /* [n] */, int64_t *total);
 
+/* ---- one process, several GPUs (contigs never interact, phanotate.py:40,56) ----
+ * A pool = one host thread and two contexts per listed device (an ordinal may repeat).  phx_pool_annotate cuts the n contigs into
+ * consecutive batches of at most batch_bases bases (<= 0: 4e8; with several devices at least two batches per device), sends batch k
+ * to device k mod n_dev with two batches in flight per device (phx_run_async), and fills out[0..n) in input order exactly as
+ * phx_annotate would (the reference's genes, see phx_download).  No process group, no collective.  trna_*: as phx_set_trnas for the
+ * whole input (offsets has n + 1 entries), or NULL.  On an error every result is freed and the first error code is returned.
+ * flags: PHX_CREATE_* without USE_STREAM. */
+typedef struct phx_pool phx_pool;
+int phx_pool_create(const phx_params *params, int32_t n_dev, const int32_t *devices, uint32_t flags, phx_pool **out);
+void phx_pool_destroy(phx_pool *pool);
+const char *phx_pool_last_error(const phx_pool *pool);
+int phx_pool_annotate(phx_pool *pool, int32_t n, const char *const *seq, const int64_t *len, int64_t batch_bases,
+                      const int64_t *trna_offsets, const int32_t *trna_start, const int32_t *trna_stop, phx_result *out /* [n] */);
+
 /* Is every gene list what the REFERENCE'S integers give?  The reference solves on trunc(Decimal(w) * 1000) with 28 digits
  * (edges.py:17-23); the device derives its integers in fp64 and, where fp64 cannot decide the truncation, in double-double, and
  * flags the edges whose integer it still cannot prove equal to the reference's (the error bound of the Decimal chain

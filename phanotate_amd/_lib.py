@@ -104,6 +104,10 @@ def lib():
         "phx_default_params": (None, [P(Params)]),
         "phx_params_from_flags": (C.c_int, [C.c_char_p, C.c_char_p, i32, P(Params)]),
         "phx_set_exact": (C.c_int, [vp, C.c_int]),
+        "phx_pool_create": (C.c_int, [P(Params), i32, P(i32), C.c_uint32, P(vp)]),
+        "phx_pool_destroy": (None, [vp]),
+        "phx_pool_last_error": (C.c_char_p, [vp]),
+        "phx_pool_annotate": (C.c_int, [vp, i32, P(C.c_char_p), P(i64), i64, vp, vp, vp, P(Result)]),
         "phx_dump_text": (C.c_int, [vp, i32, P(vp), P(i64)]),
         "phx_dec_eval": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]),
         "phx_dd_eval": (C.c_int, [C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, P(C.c_double), P(C.c_double)]),
@@ -154,7 +158,7 @@ def lib():
     return L
 
 
-EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_params_from_flags", "phx_set_exact", "phx_dump_text", "phx_dec_eval", "phx_dd_eval", "phx_dd_shortest", "phx_create", "phx_create_ex", "phx_destroy",
+EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_params_from_flags", "phx_set_exact", "phx_pool_create", "phx_pool_destroy", "phx_pool_last_error", "phx_pool_annotate", "phx_dump_text", "phx_dec_eval", "phx_dd_eval", "phx_dd_shortest", "phx_create", "phx_create_ex", "phx_destroy",
            "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_run_async", "phx_wait", "phx_download", "phx_download_flat", "phx_certified", "phx_tap_globals",
            "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
            "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_synth_contig", "phx_rbs_table", "phx_fasta_read", "phx_fasta_count",

@@ -33,6 +33,67 @@ def synth_contig(seed, L=50000):
     return buf.raw
 
 
+class Pool:
+    """phx_pool: ONE call annotates a list of contigs over several GPUs from this process — a host thread and two contexts per device
+    inside the library, batches round the devices, results in input order.  devices: GPU ordinals (one may repeat)."""
+
+    def __init__(self, params=None, devices=(0,), flags=()):
+        self.L = _lib.lib()
+        self.params = params or make_params()
+        fl = 0
+        for f in flags:
+            fl |= Annotator.FLAGS[f]
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self.L.phx_pool_create(C.byref(self.params), len(devices), devs, fl, C.byref(h))
+        if rc:
+            raise PhxError(rc, "%s (%s)" % (self.L.phx_strerror(rc).decode(), self.L.phx_last_error(None).decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.phx_pool_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def annotate(self, seqs, trnas=None, batch_bases=0):
+        """[(status, genes structured array)] per contig, in input order (phx_pool_annotate)."""
+        seqs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(seqs)
+        arr = (C.c_char_p * max(n, 1))(*seqs)
+        lens = (C.c_int64 * max(n, 1))(*[len(s) for s in seqs])
+        res = (_lib.Result * max(n, 1))()
+        to = ta = tz = None
+        if trnas is not None:
+            offs = np.zeros(n + 1, np.int64)
+            np.cumsum([len(t) for t in trnas], out=offs[1:])
+            a = np.ascontiguousarray([h[0] for t in trnas for h in t] or [0], np.int32)
+            z = np.ascontiguousarray([h[1] for t in trnas for h in t] or [0], np.int32)
+            to, ta, tz = (x.ctypes.data_as(C.c_void_p) for x in (offs, a, z))
+        rc = self.L.phx_pool_annotate(self.h, n, arr, lens, int(batch_bases), to, ta, tz, res)
+        if rc:
+            raise PhxError(rc, "phx_pool_annotate: %s (%s)" % (self.L.phx_strerror(rc).decode(), self.L.phx_pool_last_error(self.h).decode()))
+        out = []
+        for i in range(n):
+            g = np.zeros(res[i].n_genes, _lib.GENE_DT)
+            if res[i].n_genes:
+                C.memmove(g.ctypes.data, res[i].genes, res[i].n_genes * _lib.GENE_DT.itemsize)
+            out.append((int(res[i].status), g))
+        self.L.phx_free_results(res, n)
+        return out
+
+
 class Annotator:
     """One libphx context = one (host thread, GPU).
 

@@ -1448,6 +1448,93 @@ int phx_certified(phx_ctx *c, int8_t *cert) {
     return PHX_OK;
 }
 
+// ---- one process, several GPUs: a host thread and two contexts per device, batches round the devices ----
+struct phx_pool {
+    struct Lane { int device = 0; phx_ctx *ctx[2] = {nullptr, nullptr}; };
+    std::vector<Lane> lanes;
+    std::string err;
+};
+
+int phx_pool_create(const phx_params *params, int32_t n_dev, const int32_t *devices, uint32_t flags, phx_pool **out) {
+    if (!out || n_dev < 1 || !devices || (flags & PHX_CREATE_USE_STREAM)) return PHX_E_ARG;
+    *out = nullptr;
+    phx_pool *p = new phx_pool();
+    p->lanes.resize((size_t)n_dev);
+    for (int i = 0; i < n_dev; i++) {
+        p->lanes[(size_t)i].device = devices[i];
+        for (int k = 0; k < 2; k++) {
+            const int rc = phx_create_ex(params, devices[i], nullptr, flags, &p->lanes[(size_t)i].ctx[k]);
+            if (rc) { phx_pool_destroy(p); return rc; }
+        }
+    }
+    *out = p;
+    return PHX_OK;
+}
+
+void phx_pool_destroy(phx_pool *p) {
+    if (!p) return;
+    for (auto &ln : p->lanes) for (int k = 0; k < 2; k++) if (ln.ctx[k]) phx_destroy(ln.ctx[k]);
+    delete p;
+}
+
+const char *phx_pool_last_error(const phx_pool *p) { return p ? p->err.c_str() : ""; }
+
+int phx_pool_annotate(phx_pool *p, int32_t n, const char *const *seq, const int64_t *len, int64_t batch_bases,
+                      const int64_t *trna_offsets, const int32_t *trna_start, const int32_t *trna_stop, phx_result *out) {
+    if (!p || n < 0 || (n > 0 && (!seq || !len || !out))) return PHX_E_ARG;
+    if (n == 0) return PHX_OK;
+    for (int i = 0; i < n; i++) { out[i].status = 0; out[i].n_genes = 0; out[i].genes = nullptr; }
+    const size_t nl = p->lanes.size();
+    // consecutive batches of at most batch_bases bases; with several lanes at least two per lane, so that every GPU has two in flight
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) total += len[i] > 0 ? len[i] : 0;
+    int64_t limit = batch_bases > 0 ? batch_bases : 400000000ll;
+    if (nl > 1) limit = std::max<int64_t>(1, std::min<int64_t>(limit, (total + 2 * (int64_t)nl - 1) / (2 * (int64_t)nl)));
+    std::vector<std::pair<int, int>> cuts; // [lo, hi)
+    for (int lo = 0; lo < n;) {
+        int hi = lo; int64_t size = 0;
+        while (hi < n && (hi == lo || size + len[hi] <= limit)) { size += len[hi]; hi++; }
+        cuts.push_back({lo, hi});
+        lo = hi;
+    }
+    std::atomic<int> first_err{0};
+    std::mutex em;
+    auto lane_work = [&](size_t j) {
+        phx_pool::Lane &ln = p->lanes[j];
+        std::vector<size_t> mine;
+        for (size_t k = j; k < cuts.size(); k += nl) mine.push_back(k);
+        auto fail = [&](int rc, phx_ctx *c) { int z = 0; if (first_err.compare_exchange_strong(z, rc)) { std::lock_guard<std::mutex> g(em); p->err = phx_last_error(c); } };
+        auto collect = [&](size_t t) { // batch mine[t] ran on ctx[t & 1]
+            phx_ctx *c = ln.ctx[t & 1];
+            const int rc = phx_download(c, out + cuts[mine[t]].first);
+            if (rc) fail(rc, c);
+        };
+        std::vector<int64_t> toffs;
+        for (size_t t = 0; t < mine.size() && !first_err.load(); t++) {
+            if (t >= 2) collect(t - 2);
+            phx_ctx *c = ln.ctx[t & 1];
+            const int lo = cuts[mine[t]].first, hi = cuts[mine[t]].second;
+            int rc = phx_upload(c, hi - lo, seq + lo, len + lo);
+            if (!rc && trna_offsets) {
+                toffs.assign((size_t)(hi - lo) + 1, 0);
+                for (int i = lo; i <= hi; i++) toffs[(size_t)(i - lo)] = trna_offsets[i] - trna_offsets[lo];
+                rc = phx_set_trnas(c, toffs.data(), trna_start + trna_offsets[lo], trna_stop + trna_offsets[lo]);
+            }
+            if (!rc) rc = phx_run_async(c);
+            if (rc) { fail(rc, c); break; }
+        }
+        if (!first_err.load()) for (size_t t = mine.size() >= 2 ? mine.size() - 2 : 0; t < mine.size(); t++) collect(t);
+        else for (int k = 0; k < 2; k++) (void)phx_wait(ln.ctx[k]);
+    };
+    std::vector<std::thread> th;
+    for (size_t j = 1; j < nl; j++) { try { th.emplace_back(lane_work, j); } catch (...) { first_err = PHX_E_NOMEM; break; } }
+    lane_work(0);
+    for (std::thread &t : th) t.join();
+    const int rc = first_err.load();
+    if (rc) phx_free_results(out, n);
+    return rc;
+}
+
 int phx_set_exact(phx_ctx *c, int on) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }

@@ -135,6 +135,19 @@ def test_one_process_spreads_batches_over_lanes(tmp_path):
             assert len(got) == len(want)
             for (ws, wo, wg), (gs, go, gg) in zip(want, got):
                 assert np.array_equal(ws, gs) and np.array_equal(wo, go) and wg.tobytes() == gg.tobytes()
+    # the same below the C-ABI: phx_pool_annotate (a host thread + two contexts per lane inside the library), with tRNA hits
+    flat = [s for b in batches for s in b]
+    one = pa.Annotator()
+    hits = [[(100, 180)] if len(s) > 400 else [] for s in flat]
+    want_flat = one.annotate(flat, trnas=hits)
+    one.close()
+    with pa.Pool(devices=[0, 0]) as pool:
+        for bb in (0, 150000):  # one batch per lane pair, and many small batches
+            got = pool.annotate(flat, trnas=hits, batch_bases=bb)
+            assert len(got) == len(want_flat)
+            for (ws, wg), (gs, gg) in zip(want_flat, got):
+                assert ws == gs and wg.tobytes() == gg.tobytes()
+        assert pool.annotate([]) == []
     fa = tmp_path / "in.fasta"
     total = 0
     with open(fa, "w") as f:
