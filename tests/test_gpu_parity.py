@@ -1131,6 +1131,39 @@ def test_certificate_kernel_equals_its_python_statement(pa):
     a.close()
 
 
+def test_refine_bounds_hold_on_every_fixture(pa):
+    """k_refine's statements against Python's decimal on the reference's own inputs — tRNA nodes (their pairs are scored 'same',
+    functions.py:388-399; the tRNA edge is the constant -20), bridges over non-coding runs, terminal edges, non-default codon tables and
+    -s weights with 28 digits (the neartie pair), the 1e126 ORF of edge_wide: for every edge of every non-error fixture the reference's
+    integer lies inside the device's bounds, and equals the solver's integer wherever the flag is cleared; every fixture is certified
+    or solved again, and the genes are the fixture's."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import certify_probe
+    from phanotate_amd import dump
+
+    n_edges = n_flag = 0
+    for case in golden_cases():
+        g, name, seq = load_golden(case)
+        if str(g["error"]) or len(seq) > 60000:
+            continue
+        kw = golden_params(g)
+        tr = golden_trnas(g)
+        ann = pa.Annotator(pa.make_params(**kw))
+        (status, genes), = ann.annotate([seq], trnas=None if tr is None else [tr])
+        assert status >= 0 and ann.certified()[0] in (1, 2), case
+        assert np.array_equal(genes["left"], g["gene_left"]) and np.array_equal(genes["right"], g["gene_right"]), case
+        ed = ann.edges(0)
+        if len(ed):
+            viol = certify_probe.bounds_hold(ed, dump.decimal_weights(ann, 0, seq, kw["start_codons"])[2])
+            assert not viol, (case, viol[:3])
+            n_edges += len(ed); n_flag += int(ed["inexact"].sum())
+        ann.close()
+    assert n_edges > 200000 and n_flag > 100, (n_edges, n_flag)
+
+
 def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, oracle):
     """The host leg of the guarantee, below the C-ABI: a contig the device does not certify is solved again inside phx_download* on
     the reference's Decimal-derived integers (csrc/phx_exact.inc: the Decimal chain replayed by phx_dec.c + the in-order Bellman-Ford
