@@ -60,6 +60,7 @@ class Result(C.Structure):
         ("n_gene", C.c_int32), ("gene", C.POINTER(Gene)),
         ("binF", C.POINTER(C.c_uint8)), ("binR", C.POINTER(C.c_uint8)),
         ("other_end_t", C.POINTER(C.c_int32)),
+        ("wide", C.c_int32), ("pad_wide", C.c_int32), ("dist_wide", C.c_uint64 * 20),
     ]
 
 
@@ -167,7 +168,8 @@ def run(seq, params=None, stages=3, trnas=None):
             out["edge_wint_limbs"] = ed["wint"]
         if stages >= 3:
             out["path"] = np.array(r.path[: r.n_path], dtype=np.int32)
-            out["path_dist"] = limbs_to_int(r.dist[:])
+            out["wide"] = int(r.wide)  # the sums overflowed 256 bits: solved on 1280-bit integers (edge_wint_limbs are then meaningless)
+            out["path_dist"] = limbs_to_int(r.dist_wide[:]) if r.wide else limbs_to_int(r.dist[:])
             out["bf_rounds"] = r.bf_rounds
             ge = _view(r.gene, r.n_gene, GENE_DT)
             out["gene_left"], out["gene_right"] = ge["left"], ge["right"]
