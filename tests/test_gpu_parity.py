@@ -1253,6 +1253,29 @@ def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
     assert n_changed == 1, "the host re-solve must change exactly one of the two results"
 
 
+def test_a_cycle_of_negative_length_is_reported(pa, oracle):
+    """Overlap edges point backwards, so the ORF graph can hold a cycle, and on a contig of many short overlapping frames its length can
+    be negative (tools/fuzz_gpu.py, seed 949, contig 176: 2000 bases, 123 nodes — the first such contig in 110 000): the relaxation never
+    settles.  What fastpathz does then is unknown (the dependency is absent); libphx reports PHX_S_NEGCYCLE (-9) for that contig and goes
+    on, the oracle now says the same instead of walking parents that run in a circle."""
+    import sys
+
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_gpu
+
+    rng = np.random.RandomState(949)
+    seqs = [fuzz_gpu.make(rng) for _ in range(177)]
+    cyc = seqs[176]
+    assert oracle.run(cyc)["status"] == -9
+    for flags in ((), ("solver_no_wave",), ("solver_global",)):
+        ann = pa.Annotator(flags=flags)
+        res = ann.annotate([seqs[175], cyc, seqs[174]])
+        assert [r[0] for r in res] == [oracle.run(seqs[175])["status"], -9, oracle.run(seqs[174])["status"]] and len(res[1][1]) == 0, flags
+        assert ann.certified()[1] == 1
+        ann.close()
+
+
 def test_path_sums_beyond_1088_bits_are_reported_not_computed(pa):
     """The reference's solver has no width limit (GMP, CHANGELOG.md:11-13); libphx stops at 1088-bit integers: a contig that needs more
     (an open reading frame of 24 000 codons without a stop) gets PHX_S_OVERFLOW (-7) and no genes, the rest of the batch is not touched."""

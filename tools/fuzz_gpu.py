@@ -50,6 +50,8 @@ def orc(seq):
     o = oracle.run(seq)
     if o["status"] == -7:  # the oracle's 256-bit integers overflow: not compared here (tests/ has python-int solves for such cases)
         return 0, None
+    if o["status"] < 0:  # no genes: only the status is compared (-9: the relaxation never settles, a cycle of negative length)
+        return int(o["status"]), ([], [], [], None)
     return int(o["status"]), (np.asarray(o["gene_left"]).tolist(), np.asarray(o["gene_right"]).tolist(), np.asarray(o["gene_strand"]).tolist(), int(o["path_dist"]) if len(o["path"]) else None)
 
 def main():
