@@ -280,6 +280,18 @@ def test_attach_device_resident_input(pa):
     for (s1, g1), (s2, g2) in zip(want, got):
         assert s1 == s2 and g1.tobytes() == g2.tobytes()
     ann.close()
+    # the guarantee holds on the zero-copy path too: contigs the certificate leaves open (most of them with the inflated bounds of
+    # cert_tight) are solved again on the host from bases the library fetches back from the caller's buffer (this path used
+    # to skip the re-solve silently)
+    tight = pa.Annotator(flags=("cert_tight",))
+    tight.attach(buf.data_ptr(), offs)
+    tight.run()
+    st, o2, g2 = tight.download_flat()
+    assert len(tight.resolved) >= 1 and (tight.certified() != 0).all()
+    for i, (s1, g1) in enumerate(want):
+        g = g2[o2[i] : o2[i + 1]]
+        assert st[i] == s1 and all(np.array_equal(g[f], g1[f]) for f in ("left", "right", "strand", "frame"))
+    tight.close()
 
 
 def _bellman_ford(V, src, dst, w, s, t):
