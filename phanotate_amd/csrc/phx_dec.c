@@ -481,6 +481,11 @@ int dec_pow(dec_t *r, const dec_t *a, const dec_t *b, int prec) { /* mpd_qpow fo
         q = *b; if (q.exp > 0) { q.n = bn_shl10(q.d, q.n, q.exp); q.exp = 0; } else if (q.exp < 0) { int dt, st; q.n = bn_shr10(q.d, q.n, -q.exp, &dt, &st); q.exp = 0; }
         if (q.n > 2) return -1;
         const uint64_t n = (uint64_t)q.d[0] + (q.n > 1 ? (uint64_t)q.d[1] * BASE : 0);
+        { /* the result's exponent must stay inside Emin / Emax of the reference's context (+-999999): beyond that libmpdec rounds to
+             subnormals or signals Overflow, which is not restated here (and the int exponents below would wrap) */
+            const double adj = (double)a->exp + (double)dec_digits(a) - 1.0;
+            if (fabs(adj) * (double)n > 999999.0 || n > 100000000ull) return -1;
+        }
         if (b->sign) { wprec += 1; dec_t one; dec_from_i64(&one, 1); if (dec_div(&tb, &one, a, wprec)) return -1; } else tb = *a;
         pow_uint(r, &tb, n, wprec);
         dec_round(r, prec);
