@@ -722,6 +722,9 @@ void phx_destroy(phx_ctx *c) {
     delete c;
 }
 
+#ifndef PHX_PLAN_STREAM_MAX
+#define PHX_PLAN_STREAM_MAX 800 // batches of up to this many contigs: k_sssp_wave<2,0> runs beside k_wave_plan<2,0> (run_pipeline).  Beyond, the planner is done before the edge fill is (1000 x 50 kb: 0.35 against 0.43 ms) and there is nothing to gain (measured: +0.4 % on the step)
+#endif
 #ifndef PHX_UPLOAD_THREADS
 #define PHX_UPLOAD_THREADS 16
 #endif
@@ -1034,23 +1037,32 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
     }
     fill_batch(c, &b);
-    // the windows of the wavefront solver need the node records and in-edge counts only: laid out beside the edge fill
-    HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
-    HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
-    {
-        StageTimer t(c, ST_WAVE_PLAN, c->aux[3]); // (on the side stream: runs beside "edges_fill", not in the sum of the main stream's stages)
-        phxk_wave_plan(&b, ((mask >> 6) & 1) | (((mask >> 10) & 1) << 1), c->aux[3]); // bits 4*1+2, 4*2+2: 256- / 512-bit contigs for the wavefront kernel
-        if (b.sord) phxk_sssp_order(&b, c->aux[3]);
-    }
-    HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
-    {
-        b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
-        { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
-    }
+    // A contig's planner (one wavefront walking all its windows: 0.14 ms for Lambda, 0.25 ms for T4, 0.2-0.35 ms in a batch) outlasts the
+    // edge fill it runs beside unless the batch is large (0.06 / 0.09 ms for a lone contig, 0.2 ms for 512 contigs), so the solver used to
+    // start that much late.  The tight 128-bit solver is launched right behind the edge fill instead and follows the planner's progress
+    // counter (DMeta.plan_prog).  Every planner wavefront has been resident for the whole edge fill by then (both kernels fit the chip
+    // side by side up to one contig per SIMD); a solver that sees no progress for 20 ms hands its contig to the workgroup kernel.
+    const bool stream_plan = c->n <= PHX_PLAN_STREAM_MAX && !b.sord && !c->one_stream && c->aux[3] && ((mask >> 2) & 1);
+    b.plan_stream = stream_plan ? 1 : 0;
+    b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
+    auto launch_plan = [&]() -> int { // the windows of the wavefront solver need the node records and in-edge counts only
+        HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux[3], c->ev_fork_plan, 0));
+        {
+            StageTimer t(c, ST_WAVE_PLAN, c->aux[3]); // (on the side stream: runs beside "edges_fill" / "sssp", not in the sum of the main stream's stages)
+            phxk_wave_plan(&b, ((mask >> 6) & 1) | (((mask >> 10) & 1) << 1), c->aux[3]); // bits 4*1+2, 4*2+2: 256- / 512-bit contigs for the wavefront kernel
+            if (b.sord) phxk_sssp_order(&b, c->aux[3]);
+        }
+        HIPCHK(c, hipEventRecord(c->ev_join[3], c->aux[3]));
+        return PHX_OK;
+    };
+    if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
+    { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
         StageTimer t(c, ST_SSSP);
+        if (stream_plan) phxk_sssp(&b, 2, 2, (size_t)lds[0], s); // beside the planner, see above
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[3], 0)); // k_wave_plan: also decides which contigs the wavefront kernel takes
         const int nl_of[4] = {2, 4, 8, 17};
         int nlaunch = 0, nclass = 0;
@@ -1084,7 +1096,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
                 st = c->aux[a];
             }
             for (int mode = 3; mode >= 0; mode--) // 3: the wavefront kernel's roomy configuration (few contigs, if any), 2: its tight one
-                if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side)) {
+                if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side) && !(stream_plan && k == 0 && mode == 2)) {
                     if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                 }

@@ -158,6 +158,9 @@ struct DMeta { // one per contig
     int32_t tie;       // k_inorder: 0 the shortest path is unique, 1 equal-length alternatives exist and the solver's path is the in-order one,
                        // 2 the path was replaced by the in-order one, -1 not resolved (cannot happen)
     int32_t cert;      // k_certify: 1 the path is proven to be the one the reference's Decimal-derived integers give, 0 not proven (phx_certify.inc)
+    int32_t plan_prog; // DBatch.plan_stream: windows whose records k_wave_plan<2,0> has published (| WV_PLAN_DONE when it has finished; -1: it
+                       // gave the contig up) — k_sssp_wave<2,0> runs beside the planner and consumes the windows as they appear
+    int32_t pad_;
 };
 
 // What the host needs of a contig after every run (the full DMeta record, 0.5 KB, comes over only when a tap asks for it)
@@ -293,6 +296,8 @@ struct DBatch {
     int32_t *path;
     DGene *genes;
     uint32_t *gene_total;
+    int32_t plan_stream; // small batches (a lone contig's planner is longer than the edge fill it hides behind): k_sssp_wave<2,0> is launched without
+                         // waiting for k_wave_plan<2,0> and follows DMeta.plan_prog
     int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c
     DGene *genes_c;
 };
