@@ -1397,6 +1397,21 @@ def test_wavefront_kernel_in_both_configurations_equals_the_oracle(pa, oracle):
         check_exact_distances(ann, i)
         assert np.array_equal(genes["left"], o["gene_left"]) and np.array_equal(genes["right"], o["gene_right"]) and np.array_equal(genes["strand"], o["gene_strand"]), i
     ann.close()
+    # Batches of up to 800 contigs launch the tight solver BESIDE its planner and let it follow the planner's progress counter
+    # (DMeta.plan_prog).  A contig the tight planner gives up half-way is the hard case: its solver has consumed windows already when
+    # the counter turns to -1, must leave the contig alone, and the roomy pair takes over.  Alone in a batch (the planner then runs far
+    # longer than the edge fill, the solver really waits on the counter), on repeated runs of the captured graph, and with the side
+    # streams folded into one (one_stream: nothing is streamed) the records must be the batch's.
+    lone = pa.Annotator()
+    serial = pa.Annotator(flags=("one_stream",))
+    for i in kinds[3][:4] + kinds[2][:2]:
+        for a in (lone, serial):
+            (st, g), = a.annotate([seqs[i]])
+            assert st == res[i][0] and g.tobytes() == res[i][1].tobytes(), i
+            a.run(); a.run()
+            (st2, g2), = a.download()
+            assert st2 == st and g2.tobytes() == g.tobytes(), i
+    lone.close(); serial.close()
 
 
 def test_features_behind_the_upload_equal_features_inside_the_run(pa):
