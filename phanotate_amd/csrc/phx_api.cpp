@@ -470,12 +470,12 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
     if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
-    if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes)))) return rc;
+    if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes) + sizeof(DTotals)))) return rc; // (k_results appends the totals: one copy brings both to the host)
     if (c->res_cap < (size_t)c->n + 1) {
         if (c->res) (void)hipHostFree(c->res);
         c->res = nullptr; c->res_cap = 0;
         const size_t want = (size_t)c->n + (size_t)c->n / 4 + 16;
-        if (hipHostMalloc((void **)&c->res, want * sizeof(DRes), hipHostMallocDefault) != hipSuccess) { c->res = nullptr; c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
+        if (hipHostMalloc((void **)&c->res, want * sizeof(DRes) + sizeof(DTotals), hipHostMallocDefault) != hipSuccess) { c->res = nullptr; c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
         c->res_cap = want;
     }
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
@@ -1117,8 +1117,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     { // per-contig records (statuses, offsets, gene counts) and the totals
         StageTimer t(c, ST_COPY);
         phxk_results(&b, s);
-        HIPCHK(c, hipMemcpyAsync(c->res, c->b_res.p, sizeof(DRes) * (size_t)n, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->res, c->b_res.p, sizeof(DRes) * (size_t)n + sizeof(DTotals), hipMemcpyDeviceToHost, s)); // records + the totals k_results put behind them (finish_once)
     }
     return PHX_OK;
 }
@@ -1226,6 +1225,7 @@ int finish_once(phx_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(s));
     collect_timers(c);
     c->meta_stale = true;
+    memcpy(c->h_tot, (const void *)(c->res + (size_t)c->n), sizeof(DTotals)); // the totals came with the per-contig records
     const DTotals *ht = c->h_tot;
     c->tie_seen = std::max(c->tie_seen, ht->tie_need);
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
