@@ -140,7 +140,8 @@ typedef struct phx_globals {
     int32_t status;
     int32_t sssp_kernel; /* which kernel solved it: 0 global memory, 1 workgroup per contig, 2 wavefront per contig, 3 the same in its roomy configuration */
     int32_t sssp_handed_back; /* != 0: the wavefront kernel passed the contig on: 1 a node's 500 bp neighbourhood exceeds a window,
-                               * 2 spill list full, 3 no convergence, 4 too many step-backs */
+                               * 2 spill list full, 3 no convergence, 4 too many step-backs, 5 its planner made no progress for 20 ms
+                               * (small batches run the two side by side; never seen outside test builds) */
     int32_t tie; /* equal-length alternatives to the shortest path (the reference's relaxation order decides, see phx_inorder.inc):
                   * 0 none, 1 they exist and the solver's path already was the reference's, 2 the path was replaced by the reference's */
     int32_t certified; /* phx_certified's verdict for this contig (1 / 0 / -1) */

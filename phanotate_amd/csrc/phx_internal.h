@@ -147,7 +147,7 @@ struct DMeta { // one per contig
     int32_t n_orf_main, n_grp_main; // ORFs / groups emitted by the main loop (the end fragments follow)
     int32_t sssp_nl;   // 64-bit limbs this contig's path sums need (2, 4, 8 or 17)
     int32_t sssp_iters;
-    int32_t sssp_why;  // why k_sssp_wave handed the contig back: 1 window limits, 2 spill list, 3 no convergence, 4 too many step-backs (0: it did not)
+    int32_t sssp_why;  // why k_sssp_wave handed the contig back: 1 window limits, 2 spill list, 3 no convergence, 4 too many step-backs, 5 no progress of the planner it follows (0: it did not)
     int32_t sssp_mode; // 0 = global-memory kernel, 1 = workgroup-per-contig LDS kernel, 2 = wavefront-per-contig kernel, 3 = that kernel's roomy configuration
     int32_t n_open;    // entries of olist that are open nodes (incl. the target); the close nodes follow
     int32_t dense;     // some node has more than ~62 close / open nodes within the next 500 bp: k_sssp_wave's windows cannot take it (k_edges<false>)
