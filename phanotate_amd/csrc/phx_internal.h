@@ -161,7 +161,6 @@ struct DMeta { // one per contig
     int32_t plan_prog; // DBatch.plan_stream: windows whose records k_wave_plan<2,0> has published (| WV_PLAN_DONE when it has finished; -1: it
                        // gave the contig up) — k_sssp_wave<2,0> runs beside the planner and consumes the windows as they appear
     int32_t pad_;
-    double cmax;       // largest |connector weight * 1000| this contig can have (k_score computes it once per contig; k_layout2, one workgroup for the whole batch, only reads it)
 };
 
 // What the host needs of a contig after every run (the full DMeta record, 0.5 KB, comes over only when a tap asks for it)
