@@ -1363,6 +1363,7 @@ int phx_download(phx_ctx *c, phx_result *out) {
         HIPCHK(c, hipMemcpyAsync(c->h_genes, (const DGene *)c->b_genes.p + (gene_pack(c) ? gene_half(c) : 0), sizeof(DGene) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    for (int i = 0; i < c->n; i++) { out[i].status = 0; out[i].n_genes = 0; out[i].genes = nullptr; } // (so that a failure half-way leaves nothing dangling)
     for (int i = 0; i < c->n; i++) {
         const DRes &m = c->res[(size_t)i];
         out[i].status = m.status;
@@ -1372,7 +1373,7 @@ int phx_download(phx_ctx *c, phx_result *out) {
         out[i].genes = nullptr;
         if (out[i].n_genes > 0) {
             out[i].genes = (phx_gene *)malloc(sizeof(phx_gene) * (size_t)out[i].n_genes);
-            if (!out[i].genes) return PHX_E_NOMEM;
+            if (!out[i].genes) { out[i].n_genes = 0; phx_free_results(out, c->n); return PHX_E_NOMEM; }
             for (int k = 0; k < out[i].n_genes; k++) {
                 const DGene &g = src[k];
                 out[i].genes[k].left = g.left; out[i].genes[k].right = g.right;
