@@ -1463,3 +1463,21 @@ def test_512_bit_contigs_on_the_wavefront_kernel(pa, oracle, ncodons):
     check_exact_distances(ann, 0)
     assert ann.certified()[0] in (0, 1)
     ann.close()
+
+
+def test_512_bit_contig_whose_stop_node_has_450_in_edges(pa, oracle):
+    """The same with ordinary codon usage in the long frame: 5 % of its 9000 codons are starts, the stop node behind it collects ~450
+    ORF in-edges — more than a window's lanes (64 x 4) hold; the rest goes to the spill list, which k_sssp_wave<8> has room for since
+    round 4 (448 entries; the contig used to fall to k_sssp_lds<8>: 1.93 ms of solver instead of 1.53).  Exact distances, exact genes."""
+    rng = np.random.RandomState(42)
+    sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
+    seq = pa.synth_contig(900, 20000).decode() + "atg" + "".join(rng.choice(sense, 9000)) + "taa" + pa.synth_contig(1900, 20000).decode()
+    ann = pa.Annotator()
+    (status, genes), = ann.annotate([seq])
+    gl = ann.globals(0)
+    assert status == 0 and gl.n_limbs == 8 and gl.sssp_kernel == 2 and gl.sssp_handed_back == 0, (gl.n_limbs, gl.sssp_kernel, gl.sssp_handed_back)
+    o = oracle.run(seq, stages=2)
+    dist, want = _py_bellman_ford_genes(o)
+    assert [(int(g["left"]), int(g["right"])) for g in genes] == want
+    check_exact_distances(ann, 0)
+    ann.close()
