@@ -1042,8 +1042,15 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // start that much late.  The tight 128-bit solver is launched right behind the edge fill instead and follows the planner's progress
     // counter (DMeta.plan_prog).  Every planner wavefront has been resident for the whole edge fill by then (both kernels fit the chip
     // side by side up to one contig per SIMD); a solver that sees no progress for 20 ms hands its contig to the workgroup kernel.
-    const bool stream_plan = c->n <= PHX_PLAN_STREAM_MAX && !b.sord && !c->one_stream && c->aux[3] && ((mask >> 2) & 1);
-    b.plan_stream = stream_plan ? 1 : 0;
+    // Which class follows its planner: the 128-bit contigs' tight configuration whenever the batch has such contigs; a batch that is ALL
+    // 256-bit or all 512-bit contigs (a lone genome with a 2000+ codon ORF) streams that class's pair instead.
+    int stream_k = -1;
+    if (c->n <= PHX_PLAN_STREAM_MAX && !b.sord && !c->one_stream && c->aux[3]) {
+        if ((mask >> 2) & 1) stream_k = 0;
+        else for (int k = 1; k <= 2; k++) if (((mask >> (4 * k + 2)) & 1) && !(mask & 0xffff & ~(15 << (4 * k)))) stream_k = k;
+    }
+    const bool stream_plan = stream_k >= 0;
+    b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
     b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
     auto launch_plan = [&]() -> int { // the windows of the wavefront solver need the node records and in-edge counts only
         HIPCHK(c, hipEventRecord(c->ev_fork_plan, s));
@@ -1062,7 +1069,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
         StageTimer t(c, ST_SSSP);
-        if (stream_plan) phxk_sssp(&b, 2, 2, (size_t)lds[0], s); // beside the planner, see above
+        if (stream_plan) phxk_sssp(&b, 2 << stream_k, 2, (size_t)lds[stream_k], s); // beside the planner, see above
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[3], 0)); // k_wave_plan: also decides which contigs the wavefront kernel takes
         const int nl_of[4] = {2, 4, 8, 17};
         int nlaunch = 0, nclass = 0;
@@ -1096,7 +1103,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
                 st = c->aux[a];
             }
             for (int mode = 3; mode >= 0; mode--) // 3: the wavefront kernel's roomy configuration (few contigs, if any), 2: its tight one
-                if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side) && !(stream_plan && k == 0 && mode == 2)) {
+                if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side) && !(stream_plan && k == stream_k && mode == 2)) {
                     if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                 }

@@ -296,8 +296,8 @@ struct DBatch {
     int32_t *path;
     DGene *genes;
     uint32_t *gene_total;
-    int32_t plan_stream; // small batches (a lone contig's planner is longer than the edge fill it hides behind): k_sssp_wave<2,0> is launched without
-                         // waiting for k_wave_plan<2,0> and follows DMeta.plan_prog
+    int32_t plan_stream; // small batches (a lone contig's planner is longer than the edge fill it hides behind): 0, or the limb count (2, 4, 8) of the
+                         // class whose k_sssp_wave is launched without waiting for its k_wave_plan and follows DMeta.plan_prog
     int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c
     DGene *genes_c;
 };

@@ -308,7 +308,7 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         if (nl == 2 && mode == 2) {
             const size_t lb = wv_lds_bytes<2, 0>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-            if (b->plan_stream) { // small batches: beside k_wave_plan<2,0>, following its counter
+            if (b->plan_stream == 2) { // small batches: beside k_wave_plan<2,0>, following its counter
                 (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
                 hipLaunchKernelGGL((k_sssp_wave<2, 0, true>), g, dim3(64), lb, s, *b);
             } else
@@ -320,10 +320,18 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         } else if (nl == 4) {
             const size_t lb = wv_lds_bytes<4, 1>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            if (b->plan_stream == 4) {
+                (void)hipFuncSetAttribute((const void *)k_sssp_wave<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL((k_sssp_wave<4, 1, true>), g, dim3(64), lb, s, *b);
+            } else
             hipLaunchKernelGGL((k_sssp_wave<4, 1>), g, dim3(64), lb, s, *b);
         } else {
             const size_t lb = wv_lds_bytes<8, 1>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+            if (b->plan_stream == 8) {
+                (void)hipFuncSetAttribute((const void *)k_sssp_wave<8, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL((k_sssp_wave<8, 1, true>), g, dim3(64), lb, s, *b);
+            } else
             hipLaunchKernelGGL((k_sssp_wave<8, 1>), g, dim3(64), lb, s, *b);
         }
         return;
