@@ -723,7 +723,7 @@ void phx_destroy(phx_ctx *c) {
 }
 
 #ifndef PHX_PLAN_STREAM_MAX
-#define PHX_PLAN_STREAM_MAX 800 // batches of up to this many contigs: k_sssp_wave<2,0> runs beside k_wave_plan<2,0> (run_pipeline).  Beyond, the planner is done before the edge fill is (1000 x 50 kb: 0.35 against 0.43 ms) and there is nothing to gain (measured: +0.4 % on the step)
+#define PHX_PLAN_STREAM_MAX 800 // batches of up to this many contigs: k_sssp_wave<2,0> runs beside k_wave_plan<2,0> (run_pipeline).  Beyond, the planner is done before the edge fill is (1000 x 50 kb: 0.35 against 0.43 ms) and there is nothing to gain (measured with 1024: +0.7 % on the step, +2 % on two batches in flight)
 #endif
 #ifndef PHX_UPLOAD_THREADS
 #define PHX_UPLOAD_THREADS 16
