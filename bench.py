@@ -45,7 +45,7 @@ def algorithmic_bytes(sz):
     return sz["L"] / 4.0 + 4.0 * sz["L"] + 64.0 * sz["n_orf"] + 32.0 * sz["n_edge"] + 64.0 * sz["n_node"]
 
 
-STAGE_KERNEL = {"sssp": "k_sssp_wave<2, 0>", "features": "k_features", "edges_fill": "k_edges<true, false>", "edges_count": "k_edges<false, false>",
+STAGE_KERNEL = {"sssp": "k_sssp_wave<2, 0,", "features": "k_features", "edges_fill": "k_edges<true, false>", "edges_count": "k_edges<false, false>",
                 "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true,", "orf_count": "k_orf<false,", "nodes": "k_node_build", "score": "k_score",
                 "inorder": "k_inorder<2,"}  # substrings of the kernel names as rocprofv3 prints them
 
@@ -398,6 +398,11 @@ def main():
             return pmc_traffic_committed(stage, len(seqs), L_) if args.workload == "synthetic" else None
 
         dom_ms = dom_total / max(dom_n, 1)
+        dom_traffic = traffic_of(dom)
+        if live is not None and dom_traffic is None:
+            # (BENCH_r04 lost this number to a renamed kernel: the stage -> kernel-name map no longer matched the trace)
+            raise RuntimeError("bench.py: the live PMC pass ran but no kernel name contains %r (stage %s): STAGE_KERNEL is stale; kernels seen: %s"
+                               % (STAGE_KERNEL.get(dom), dom, sorted(live[0])))
         balgo = algorithmic_bytes(sz)
         achieved = balgo / (dom_ms * 1e-3) / 1e9
         step_achieved = balgo / (kernel_ms_per_step * 1e-3) / 1e9
@@ -416,6 +421,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 bases / fp64 scores / int64 edge weights / int128 distances",
             "data": ("synthetic" if args.workload == "synthetic" else "reference test genome (tests/golden)") + (" [SMOKE: all ranks on one GPU, gloo]" if args.smoke_single_device else ""),
+            "value_with_certificate": round(bp_total * args.steps / dt_cert / 1e6, 3),
+            "value_with_certificate_is": "the same resident step followed by phx_certified (k_refine + k_certify: the proof that every gene list is the one the reference's Decimal-derived integers give): the rate that carries the bit-identity guarantee; `value` is phx_run alone",
             "value_is": "inputs resident in HBM when the timed region starts (task contract); host ASCII -> host gene lists is `host_to_host`",
             "config": {
                 "workload": wl,
@@ -452,7 +459,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic_of(dom),
+                "traffic": dom_traffic,
+                "frac_by_traffic": None if not dom_traffic else round(dom_traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                "frac_by_traffic_is": "the dominant kernel's HBM bytes from the PMC counters / its average duration / peak: what the kernel really moves, beside `frac` (algorithmic bytes of the whole step / the same duration)",
                 "traffic_source": ("measured in this run: two `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) of a one-step run of this command; bytes = (2 FETCH + WRITE) KiB: the guide's gfx950 correction, which is calibrated on streaming reads and is applied here to scattered reads as well (uncalibrated for them)" if live is not None
                                    else "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; rocprofv3 not available to this process or --no-traffic)"),
                 "traffic_step_total": None if live is None else live[1],

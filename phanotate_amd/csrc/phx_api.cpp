@@ -561,7 +561,7 @@ int phx_params_from_flags(const char *start_codons, const char *stop_codons, int
             const std::string wt = item.substr(colon + 1);
             if (wt.empty() || wt.size() >= sizeof(p->start_w_text[0])) return PHX_E_PARAM;
             char *end = nullptr;
-            const double w = strtod(wt.c_str(), &end);
+            const double w = phx_strtod_c(wt.c_str(), &end); // (the "C" locale whatever the host application's LC_NUMERIC is)
             if (!end || *end || !(w == w)) return PHX_E_PARAM;
             int at = -1;
             for (int i = 0; i < p->n_start; i++) if (!strcmp(p->start[i], cod)) at = i; // dict semantics: first place, last weight

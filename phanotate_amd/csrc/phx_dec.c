@@ -2,12 +2,41 @@
  * through.  See phx_dec.h.  Coefficients are little-endian base-1e9 integers; ln / exp work in decimal fixed point and are rounded
  * correctly (the Python context sets allcr: mpd_qln / mpd_qexp return the correctly rounded value) by a Ziv loop.
  * Checked against Python's own decimal module operation by operation: tests/test_dec.py. */
+#define _GNU_SOURCE /* newlocale / uselocale / strtod_l */
 #include "phx_dec.h"
 
+#include <locale.h>
 #include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* Number text in the "C" locale whatever LC_NUMERIC the host application runs under (with a comma-decimal locale
+ * "%.*e" prints "1,5e+00", dec_from_str rejected it and the replay went on with 0).  uselocale() switches the calling thread only. */
+static locale_t c_locale(void) {
+    static locale_t loc; /* (a lost race leaks one small object) */
+    locale_t l = __atomic_load_n(&loc, __ATOMIC_ACQUIRE);
+    if (!l) {
+        l = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+        locale_t expect = (locale_t)0;
+        if (l && !__atomic_compare_exchange_n(&loc, &expect, l, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { freelocale(l); l = expect; }
+    }
+    return l;
+}
+double phx_strtod_c(const char *s, char **end) {
+    locale_t l = c_locale();
+    return l ? strtod_l(s, end, l) : strtod(s, end);
+}
+int phx_snprintf_c(char *buf, size_t cap, const char *fmt, ...) {
+    locale_t l = c_locale(), old = l ? uselocale(l) : (locale_t)0;
+    va_list ap;
+    va_start(ap, fmt);
+    const int n = vsnprintf(buf, cap, fmt, ap);
+    va_end(ap);
+    if (old) uselocale(old);
+    return n;
+}
 
 #define BASE 1000000000u
 static const uint32_t P10[10] = {1u, 10u, 100u, 1000u, 10000u, 100000u, 1000000u, 10000000u, 100000000u, 1000000000u};
@@ -429,7 +458,7 @@ int dec_ln(dec_t *r, const dec_t *a, int prec) {
         const int F = 9 * FL;
         fx_t m; { dec_t t = *a; t.exp = -nd; if (fx_from_dec(&m, &t, FL)) return -1; }
         /* y0 ~ ln m on a 1e-17 grid (exact in fixed point) */
-        double md = 0; { char dg[DEC_LIMBS * 9 + 2]; coeff_str(a, dg); char buf[40]; snprintf(buf, sizeof buf, "0.%.20s", dg); md = strtod(buf, NULL); }
+        double md = 0; { char dg[DEC_LIMBS * 9 + 2]; coeff_str(a, dg); char buf[40]; snprintf(buf, sizeof buf, "0.%.20s", dg); md = phx_strtod_c(buf, NULL); }
         const double y0 = log(md);
         const int64_t qg = llround(y0 * 1e17);
         fx_t Y0; { dec_t t; dec_from_i64(&t, qg < 0 ? -qg : qg); t.exp = -17; if (fx_from_dec(&Y0, &t, FL)) return -1; }
@@ -566,7 +595,7 @@ void dec_to_dd(const dec_t *a, double *hi, double *lo) {
 int phx_repr_double(double x, char *out, int cap) { /* float_repr_style 'short' (Python/pystrtod.c format_float_short, 'r') */
     char buf[40];
     int p;
-    for (p = 1; p <= 17; p++) { snprintf(buf, sizeof buf, "%.*e", p - 1, x); if (strtod(buf, NULL) == x) break; }
+    for (p = 1; p <= 17; p++) { phx_snprintf_c(buf, sizeof buf, "%.*e", p - 1, x); if (phx_strtod_c(buf, NULL) == x) break; }
     if (p > 17) p = 17;
     /* buf = [-]d[.ddd]e[+-]XX */
     char dg[24]; int nd = 0; const char *s = buf; int neg = 0;
@@ -593,17 +622,19 @@ int phx_repr_double(double x, char *out, int cap) { /* float_repr_style 'short' 
     return (int)(q - out);
 }
 
-void dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out) {
+int dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out) {
     static __thread dec_t t[16];
+    int bad = 0;
     if (n > 16) n = 16;
     int mx = 0;
     for (int i = 0; i < n; i++) {
         char buf[48];
-        if (texts && texts[i][0]) { if (dec_from_str(&t[i], texts[i])) dec_from_i64(&t[i], 0); }
-        else { phx_repr_double(w[i], buf, sizeof buf); dec_from_str(&t[i], buf); }
+        if (texts && texts[i][0]) { if (dec_from_str(&t[i], texts[i])) { dec_from_i64(&t[i], 0); bad = -1; } }
+        else { phx_repr_double(w[i], buf, sizeof buf); if (dec_from_str(&t[i], buf)) { dec_from_i64(&t[i], 0); bad = -1; } }
         if (dec_cmp(&t[i], &t[mx]) > 0) mx = i;
     }
-    for (int i = 0; i < n; i++) if (dec_div(&out[i], &t[i], &t[mx], DEC_PREC)) dec_from_i64(&out[i], 0);
+    for (int i = 0; i < n; i++) if (dec_div(&out[i], &t[i], &t[mx], DEC_PREC)) { dec_from_i64(&out[i], 0); bad = -1; }
+    return bad;
 }
 
 /* ------------------------------------------------------------------------------------------------ test hook (tests/test_dec.py) */
@@ -611,8 +642,8 @@ void dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *o
  * "trunc1000" (int(a * 1000) as decimal text); result text in out.  Returns the length or a negative error. */
 int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *out, int cap) {
     static __thread dec_t x, y, r;
-    if (!strcmp(op, "repr")) return phx_repr_double(strtod(a, NULL), out, cap);
-    if (!strcmp(op, "float")) { dec_from_double(&r, strtod(a, NULL)); return dec_to_str(&r, out, cap); }
+    if (!strcmp(op, "repr")) return phx_repr_double(phx_strtod_c(a, NULL), out, cap);
+    if (!strcmp(op, "float")) { dec_from_double(&r, phx_strtod_c(a, NULL)); return dec_to_str(&r, out, cap); }
     if (dec_from_str(&x, a)) return -2;
     if (b && *b && dec_from_str(&y, b)) return -2;
     int rc = 0;
@@ -624,7 +655,7 @@ int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *o
     else if (!strcmp(op, "ln")) rc = dec_ln(&r, &x, prec);
     else if (!strcmp(op, "exp")) rc = dec_exp(&r, &x, prec);
     else if (!strcmp(op, "str")) r = x;
-    else if (!strcmp(op, "dd")) { double h, l; dec_to_dd(&x, &h, &l); return snprintf(out, (size_t)cap, "%.17g %.17g", h, l); }
+    else if (!strcmp(op, "dd")) { double h, l; dec_to_dd(&x, &h, &l); return phx_snprintf_c(out, (size_t)cap, "%.17g %.17g", h, l); }
     else if (!strcmp(op, "trunc1000")) {
         uint64_t w[18];
         if (dec_trunc_limbs(&x, 3, w, 18)) return -3;

@@ -11,6 +11,7 @@
  */
 #ifndef PHX_DEC_H
 #define PHX_DEC_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,7 +58,10 @@ void dec_to_dd(const dec_t *a, double *hi, double *lo);
 int phx_repr_double(double x, char *out, int cap);
 /* file_handling.py:58-62: Decimal(weight) / max over n start codons.  texts[i]: the weight as written, or "" = the shortest decimal
  * that reads back as w[i].  out[i]: the 28-digit quotients. */
-void dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out);
+int dec_start_weights(int n, const char (*texts)[32], const double *w, dec_t *out); /* -1: a text that is no number, or every weight 0 (the outputs are then 0: nothing may be claimed from them) */
+/* strtod / snprintf in the "C" locale, whatever LC_NUMERIC the host application has set (thread-safe: uselocale) */
+double phx_strtod_c(const char *s, char **end);
+int phx_snprintf_c(char *buf, size_t cap, const char *fmt, ...);
 int phx_dec_eval(const char *op, const char *a, const char *b, int prec, char *out, int cap); /* test hook, see include/phx.h */
 
 #ifdef __cplusplus

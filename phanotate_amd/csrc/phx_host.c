@@ -16,6 +16,8 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+
+#include "phx_dec.h" /* phx_snprintf_c: number text in the "C" locale */
 #include <unistd.h>
 #include <zlib.h>
 
@@ -280,7 +282,7 @@ static void *fmt_work(void *arg) {
             *p++ = (char)(44 - g->strand); *p++ = '\t'; /* chr(44 - strand), locus.py:51 */
             memcpy(p, nm, ln); p += ln;
             *p++ = '\t';
-            p += snprintf(p, 25, "%E", g->score);
+            p += phx_snprintf_c(p, 25, "%E", g->score); /* '%E' % weight (locus.py:54) in the "C" locale */
             *p++ = '\n';
         }
     }

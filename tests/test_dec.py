@@ -179,3 +179,33 @@ def test_double_double_of_k_refine_against_60_digit_decimals():
             assert nd > 0 and D(dg.value) * D(10) ** e.value == ref and len(str(dg.value)) == nd, (repr(x), dg.value, e.value)
             assert abs((ev("repr", (x, 0.0)) - ref) / ref) < D(2) ** -102
         assert L.phx_dd_shortest(1e-11, C.byref(dg), C.byref(e)) == 0 and L.phx_dd_shortest(1e11, C.byref(dg), C.byref(e)) == 0
+
+
+def test_number_text_does_not_follow_the_host_locale(ev):
+    """repr(float) / the -s weights went through snprintf("%.*e") and strtod, which follow LC_NUMERIC: inside a host
+    application with a comma-decimal locale every RBS weight of the host re-solve read as 0.  They now use the "C" locale whatever
+    the process has set.  (Skipped where no such locale is installed — this image has only C / POSIX.)"""
+    import locale
+
+    old = locale.setlocale(locale.LC_NUMERIC)
+    for name in ("de_DE.UTF-8", "de_DE.utf8", "fr_FR.UTF-8", "fr_FR.utf8", "nl_NL.UTF-8", "ru_RU.UTF-8", "de_DE", "fr_FR"):
+        try:
+            locale.setlocale(locale.LC_NUMERIC, name)
+            break
+        except locale.Error:
+            continue
+    else:
+        pytest.skip("no comma-decimal locale installed")
+    try:
+        assert locale.localeconv()["decimal_point"] == ","
+        for x in (1.5, 0.1 + 0.2, 2.5e-7, 123456.789):
+            assert ev("repr", repr(x)) == repr(x)
+            assert ev("float", repr(x)) == str(D(x))
+        L = _lib.lib()
+        from phanotate_amd._lib import phx_params  # noqa: F401
+
+        p = phx_params()
+        assert L.phx_params_from_flags(C.byref(p), 90, b"atg:0.85,gtg:0.10,ttg:0.05", b"tag,tga,taa") == 0
+        assert abs(p.start_w[1] - 0.10 / 0.85) < 1e-15
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, old)
