@@ -309,10 +309,6 @@ int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, i
 /* ---- host utilities (no device needed) ---- */
 /* Deterministic synthetic phage-like contig: exactly L lower-case acgt chars. */
 int phx_synth_contig(uint64_t seed, int64_t L, char *out);
-/* The 4096-entry leftward-6-mer RBS score table the position kernel uses (4 offset classes packed
- * in one uint32, class A=offsets 3-4 in bits 0-7, B=5-10, C=11-12, D=13-15); for CPU-side tests. */
-int phx_rbs_table(uint32_t *t6 /* [4096] */, uint32_t *t5 /* [1024] */, uint32_t *t4 /* [256] */, uint32_t *t3 /* [64] */);
-
 /* The reference's number type on the host (csrc/phx_dec.c: Python's decimal.Decimal at prec 28, ROUND_HALF_EVEN), for the tests:
  * op = "add" "sub" "mul" "div" "pow" "ln" "exp" on the decimal texts a (and b) at `prec` digits, "str" (a as Decimal.__str__ prints
  * it), "float" (Decimal(float(a))), "repr" (repr(float(a))), "trunc1000" (int(a * 1000) as 18 hex words), "dd" (a as a double-double).

@@ -120,7 +120,6 @@ struct phx_ctx {
     std::string err;
     // device constants
     DParams *d_params = nullptr;
-    uint32_t *d_t6 = nullptr, *d_t5 = nullptr, *d_t4 = nullptr, *d_t3 = nullptr;
     // batch
     int n = 0;
     bool uploaded = false, ran = false;
@@ -130,19 +129,20 @@ struct phx_ctx {
     bool meta_stale = false; // a run has finished since c->meta was last fetched
     DRes *res = nullptr;     // pinned: status / gene count / first gene of every contig after a run
     size_t res_cap = 0;
-    std::vector<DTile> tiles;
-    const void *attached = nullptr;
-    bool packed = false;     // b_ascii holds nibbles (phx_upload), not letters (phx_attach)
+    std::vector<uint32_t> ftab; // k_features' tables: voff (n + 1: first virtual word = first record - 1 of every contig), then wfirst (per 62 virtual words: the contig of the first)
+    uint32_t vtotal = 0;        // virtual words of the batch (records without the two pads)
+    bool defcod = false;        // the codon tables are the reference's defaults
+    const void *attached = nullptr; // phx_attach: the caller's letters on the device (k_pack_planes turns them into records at the head of a run)
     hipEvent_t ev_upload = nullptr; bool upload_pending = false; // recorded behind the last copy of phx_upload
     hipEvent_t ev_layout = nullptr; bool layout_pending = false; // recorded behind push_layout's copies
     hipEvent_t ev_piece[2] = {nullptr, nullptr};                  // phx_upload: a piece's copy -> its k_features launch
-    void *h_tiles = nullptr; size_t h_tiles_cap = 0;             // pinned copy of the tile table
+    void *h_tiles = nullptr; size_t h_tiles_cap = 0;             // pinned copy of ftab
     bool eager_now = false;    // ... and this launch is that run (launch_once)
     bool eager_done = false;   // phx_upload has already reset the accumulators and run k_features for this batch: the next run starts behind them
     bool trna_clean = true;    // no phx_set_trnas with hits since the layout was set
     std::unique_ptr<StagePool> pool;
     // buffers
-    DevBuf b_bridge, b_ascii, b_meta, b_tiles, b_rbs, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_owi, b_oflag, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
+    DevBuf b_bridge, b_recs, b_meta, b_tiles, b_nbits, b_nbase, b_cbits, b_orf, b_ostat, b_oweight, b_owi, b_oflag, b_onode, b_grp, b_bits, b_cpre, b_bpre, b_item, b_iprev;
     DevBuf b_ewf, b_esrcf;   // fp64 weights and plain sources of the batch last run, recomputed for the edge tap (k_edges<true, true>)
     bool tapw_valid = false; // ... are those of the run whose results the context holds
     int64_t tot_nbits = 0, tot_bridge = 0;
@@ -182,7 +182,7 @@ struct phx_ctx {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_flags = -1;
-    void *h_stage = nullptr; // pinned staging for H2D of ASCII
+    void *h_stage = nullptr; // pinned staging for H2D of the bases (records)
     size_t h_stage_cap = 0;
     DGene *h_genes = nullptr; size_t h_genes_cap = 0; // pinned staging of the gene records (D2H at link rate)
     // profiling
@@ -227,42 +227,7 @@ void release(DevBuf &b) {
     b.p = nullptr; b.cap = 0;
 }
 
-// ---- RBS motif tables: score_rbs (functions.py:48-138) as "max over matching (motif, offset class)" ----
-struct RbsRule { int score; const char *motif; int cls; }; // cls: 0 = offsets 3-4, 1 = 5-10, 2 = 11-12, 3 = 13-15
-const RbsRule kRules[] = {
-    {27, "ggagga", 1}, {26, "ggagga", 0}, {25, "ggagga", 2}, {24, "ggagg", 1}, {23, "ggagg", 0}, {22, "gagga", 1}, {21, "gagga", 0},
-    {20, "gagga", 2}, {20, "ggagg", 2},
-    {19, "ggacga", 1}, {19, "ggatga", 1}, {19, "ggaaga", 1}, {19, "ggcgga", 1}, {19, "ggggga", 1}, {19, "ggtgga", 1},
-    {18, "ggaaga", 0}, {18, "ggatga", 0}, {18, "ggacga", 0}, {18, "ggtgga", 0}, {18, "ggggga", 0}, {18, "ggcgga", 0},
-    {17, "ggaaga", 2}, {17, "ggatga", 2}, {17, "ggacga", 2}, {17, "ggtgga", 2}, {17, "ggggga", 2}, {17, "ggcgga", 2},
-    {16, "ggag", 1}, {16, "gagg", 1}, {15, "agga", 1}, {14, "ggtgg", 1}, {14, "ggggg", 1}, {14, "ggcgg", 1},
-    {13, "agg", 1}, {13, "gag", 1}, {13, "gga", 1},
-    {12, "agga", 2}, {12, "gagg", 2}, {12, "ggag", 2}, {11, "agga", 0}, {11, "gagg", 0}, {11, "ggag", 0},
-    {10, "gagga", 3}, {10, "ggagg", 3}, {10, "ggagga", 3},
-    {9, "gaaga", 1}, {9, "gatga", 1}, {9, "gacga", 1}, {8, "ggtgg", 0}, {8, "ggggg", 0}, {8, "ggcgg", 0},
-    {7, "ggtgg", 2}, {7, "ggggg", 2}, {7, "ggcgg", 2}, {6, "agg", 2}, {6, "gag", 2}, {6, "gga", 2},
-    {5, "gaaga", 0}, {5, "gatga", 0}, {5, "gacga", 0}, {4, "gaaga", 2}, {4, "gatga", 2}, {4, "gacga", 2},
-    {3, "agga", 3}, {3, "gagg", 3}, {3, "ggag", 3}, {2, "agg", 3}, {2, "gag", 3}, {2, "gga", 3},
-    {2, "ggaaga", 3}, {2, "ggatga", 3}, {2, "ggacga", 3}, {2, "ggtgg", 3}, {2, "ggggg", 3}, {2, "ggcgg", 3},
-    {1, "agg", 0}, {1, "gag", 0}, {1, "gga", 0},
-};
 inline int code_of(char c) { return c == 'a' ? 0 : c == 'c' ? 1 : c == 't' ? 2 : c == 'g' ? 3 : -1; }
-
-// table for k-mers of which the first `len` symbols are usable (symbol j at bits 2j..2j+1)
-void build_rbs_table(int len, uint32_t *out) {
-    const int n = 1 << (2 * len);
-    for (int code = 0; code < n; code++) {
-        uint32_t best[4] = {0, 0, 0, 0};
-        for (const RbsRule &r : kRules) {
-            const int m = (int)strlen(r.motif);
-            if (m > len) continue;
-            bool ok = true;
-            for (int j = 0; j < m && ok; j++) ok = ((code >> (2 * j)) & 3) == code_of(r.motif[j]);
-            if (ok && (uint32_t)r.score > best[r.cls]) best[r.cls] = (uint32_t)r.score;
-        }
-        out[code] = best[0] | (best[1] << 8) | (best[2] << 16) | (best[3] << 24);
-    }
-}
 
 int check_params(const phx_params *p) {
     if (!p || p->minlen < 6 || p->n_start < 1 || p->n_start > PHX_MAX_CODONS || p->n_stop < 1 || p->n_stop > PHX_MAX_CODONS) return PHX_E_PARAM;
@@ -381,10 +346,9 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->res = (DRes *)c->b_res.p;
     current_caps(c, &b->caps);
     b->params = c->d_params;
-    b->rbs_t6 = c->d_t6; b->rbs_t5 = c->d_t5; b->rbs_t4 = c->d_t4; b->rbs_t3 = c->d_t3;
-    b->ascii = (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p);
-    b->packed = c->packed ? 1 : 0;
-    b->rbs = (uint16_t *)c->b_rbs.p;
+    b->recs = (uint32_t *)c->b_recs.p;
+    b->voff = (const uint32_t *)c->b_tiles.p; b->wfirst = b->voff + (size_t)c->n + 1;
+    b->vtotal = c->vtotal; b->defcod = c->defcod ? 1 : 0;
     b->nbits = (uint64_t *)c->b_nbits.p; b->nbase = (uint32_t *)c->b_nbase.p; b->cbits = (uint64_t *)c->b_cbits.p;
     b->bits = (uint64_t *)c->b_bits.p; b->item = (uint2 *)c->b_item.p; b->iprev = (int32_t *)c->b_iprev.p;
     b->cpre = (uint32_t *)c->b_cpre.p; b->bpre = (uint32_t *)c->b_bpre.p;
@@ -431,10 +395,11 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
     c->has_trna = false; c->h_tnode.clear();
     if (n < 0) return PHX_E_ARG;
     if (!c->meta.assign((size_t)n)) { c->err = "hipHostMalloc failed"; return PHX_E_NOMEM; }
-    c->tiles.clear();
+    c->ftab.clear(); c->vtotal = 0;
     c->graph_valid = false; c->tiles_dirty = true; c->meta0_dirty = true; c->runs_on_layout = 0;
     c->max_len = 0;
-    int64_t off = 0, words = 0, items = 0, nbw = 0, nbr = 0;
+    int64_t off = 0, words = 0, items = 0, nbw = 0, nbr = 0, recs = 1; // (record 0 is a pad)
+    c->ftab.reserve((size_t)n + 1);
     for (int i = 0; i < n; i++) {
         int64_t L = len_or_null ? len_or_null[i] : offsets_or_null[i + 1] - offsets_or_null[i];
         if (L < 0 || L > 0x7ffffff0ll) return PHX_E_ARG;
@@ -442,9 +407,12 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         c->max_len = std::max<int64_t>(c->max_len, L);
         m.off = offsets_or_null ? offsets_or_null[i] : off;
         m.L = (int32_t)L;
-        int nt = 0;
-        for (int64_t p0 = 0; p0 < L; p0 += PHX_TILE) { c->tiles.push_back(DTile{i, (int32_t)p0}); nt++; }
-        m.nw = 8 * nt; // every feature tile writes 8 words per (class, frame)
+        const int nt = (int)((L + PHX_TILE - 1) / PHX_TILE);
+        m.nw = 8 * nt; // bitmap words per (plane, frame): whole tiles of 1536 positions (the readers take 8-word groups)
+        m.rec_off = recs; // 2 nw records of 96 positions and one all-outside record behind them
+        c->ftab.push_back((uint32_t)(recs - 1));
+        recs += 2 * (int64_t)m.nw + 1;
+        if (recs > 0x7ffffff0ll) return PHX_E_ARG;
         m.bits_off = words; m.item_off = items; m.nbits_off = nbw;
         m.bridge_off = nbr; m.bridge_cap = (int32_t)(L / 500 + 2);
         nbr += m.bridge_cap;
@@ -453,6 +421,16 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
         off += L;
         off = (off + 15) & ~(int64_t)15; // 16-byte aligned rows let the feature kernel store uint4
     }
+    c->vtotal = (uint32_t)(recs - 1);
+    c->ftab.push_back(c->vtotal);
+    { // per 62 virtual words: the contig of virtual word max(62 blk - 1, 0)
+        int ci = 0;
+        for (int64_t blk = 0; blk * 62 < (int64_t)c->vtotal + 62; blk++) {
+            const int64_t v = blk * 62 > 0 ? blk * 62 - 1 : 0;
+            while (ci + 1 < n && v >= (int64_t)c->ftab[(size_t)ci + 1]) ci++;
+            c->ftab.push_back((uint32_t)ci);
+        }
+    }
     c->tot_words = words; c->tot_items = items; c->tot_nbits = nbw; c->tot_bridge = nbr;
     c->totalL = offsets_or_null ? offsets_or_null[n] : off;
     c->n = n; // the callers set `uploaded` once the bases are where the kernels read them
@@ -460,13 +438,12 @@ int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const in
 }
 
 int ensure_position_buffers(phx_ctx *c) {
-    const size_t T = (size_t)c->totalL + 64;
     int rc;
-    if ((rc = ensure(c, c->b_rbs, T * 2))) return rc;
+    if ((rc = ensure(c, c->b_recs, ((size_t)c->vtotal + 2) * 36))) return rc;
     if ((rc = ensure(c, c->b_nbits, (size_t)(c->tot_nbits + 8) * 8))) return rc;
     if ((rc = ensure(c, c->b_nbase, (size_t)(c->tot_nbits / 3 + 8) * 4))) return rc;
     if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
-    if ((rc = ensure(c, c->b_tiles, sizeof(DTile) * (c->tiles.size() + 1)))) return rc;
+    if ((rc = ensure(c, c->b_tiles, 4 * (c->ftab.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
     if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
@@ -479,10 +456,10 @@ int ensure_position_buffers(phx_ctx *c) {
         c->res_cap = want;
     }
     if ((rc = ensure(c, c->b_bits, (size_t)(c->tot_words + 8) * 8))) return rc;
-    { // prefix popcounts of the class and base bitmaps, one record per PHX_PRE_G words (k_bit_prefix): 6 planes of nw / G + 1 records of 32 bytes, 3 nw / G + 1 records of 16 bytes per contig
+    { // prefix popcounts (k_bit_prefix): of the class bitmaps one record per PHX_PRE_G words — 6 planes of nw / G + 1 records of 32 bytes —, of the bases 2 nw + 2 entries of 16 bytes per contig
         const size_t W = (size_t)(c->tot_words / PHX_BITMAP_WORDS_PER_NW);
         if ((rc = ensure(c, c->b_cpre, (6 * (W / PHX_PRE_G + (size_t)c->n) + 2) * 32))) return rc;
-        if ((rc = ensure(c, c->b_bpre, (3 * W / PHX_PRE_G + (size_t)c->n + 2) * 16))) return rc;
+        if ((rc = ensure(c, c->b_bpre, (2 * W + 2 * (size_t)c->n + 4) * 16))) return rc; // per record of 96 positions: a, c, t, g in front of it
     }
     if ((rc = ensure(c, c->b_item, (size_t)(c->tot_items + 8) * 8))) return rc;
     if ((rc = ensure(c, c->b_iprev, (size_t)(c->tot_items + 8) * 4))) return rc;
@@ -586,14 +563,6 @@ int phx_params_from_flags(const char *start_codons, const char *stop_codons, int
     return check_params(p);
 }
 
-int phx_rbs_table(uint32_t *t6, uint32_t *t5, uint32_t *t4, uint32_t *t3) {
-    if (t6) build_rbs_table(6, t6);
-    if (t5) build_rbs_table(5, t5);
-    if (t4) build_rbs_table(4, t4);
-    if (t3) build_rbs_table(3, t3);
-    return PHX_OK;
-}
-
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
@@ -643,43 +612,15 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
         hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
-    std::vector<uint32_t> t6(4096), t5(1024), t4(256), t3(64);
-    phx_rbs_table(t6.data(), t5.data(), t4.data(), t3.data());
-    // the device tables hold score SETS (bit s = a rule of score s matches; k_features ORs them over a window and masks every offset
-    // by its class): that needs every score to belong to one offset class, and the packed best-per-class word to turn into bits
-    {
-        const uint32_t cm[4] = {RBS_CLS0, RBS_CLS1, RBS_CLS2, RBS_CLS3};
-        for (const RbsRule &r : kRules)
-            if (r.score < 1 || r.score > 27 || !((cm[r.cls] >> r.score) & 1u)) { c->err = "rbs score classes"; return fail(PHX_E_STATE); }
+    { // the reference's default codon tables (file_handling.py:51-53): k_features then uses their formulas instead of the table walk
+        phx_params d;
+        phx_default_params(&d);
+        DParams dd;
+        build_dparams(&d, &dd);
+        c->defcod = memcmp(dd.cls_tab, dp.cls_tab, sizeof dp.cls_tab) == 0; // (classes only: weights and minlen do not enter k_features)
     }
-    auto to_set = [](uint32_t packed) {
-        uint32_t m = 0;
-        for (int k = 0; k < 4; k++) { const uint32_t b = (packed >> (8 * k)) & 0xffu; if (b) m |= 1u << b; }
-        return m;
-    };
-    for (uint32_t &x : t6) x = to_set(x);
-    for (uint32_t &x : t5) x = to_set(x);
-    for (uint32_t &x : t4) x = to_set(x);
-    for (uint32_t &x : t3) x = to_set(x);
-    // compact device tables: every motif starts with ag, ga or gg (codes a0 c1 t2 g3; symbol j at bits 2j)
-    const uint32_t pair_code[3] = {0u | (3u << 2), 3u | (0u << 2), 3u | (3u << 2)};
-    std::vector<uint32_t> c6(768), c5(192), c4(48), c3(12);
-    for (uint32_t q = 0; q < 3; q++) {
-        for (uint32_t r = 0; r < 256; r++) c6[q * 256 + r] = t6[pair_code[q] | (r << 4)];
-        for (uint32_t r = 0; r < 64; r++) c5[q * 64 + r] = t5[pair_code[q] | (r << 4)];
-        for (uint32_t r = 0; r < 16; r++) c4[q * 16 + r] = t4[pair_code[q] | (r << 4)];
-        for (uint32_t r = 0; r < 4; r++) c3[q * 4 + r] = t3[pair_code[q] | (r << 4)];
-    }
-    for (uint32_t code = 0; code < 4096; code++) { // the compaction must not drop a scoring k-mer
-        const uint32_t p2 = code & 15u;
-        if (p2 != pair_code[0] && p2 != pair_code[1] && p2 != pair_code[2] && (t6[code] | t5[code & 1023] | t4[code & 255] | t3[code & 63])) { c->err = "rbs table compaction"; return fail(PHX_E_STATE); }
-    }
-    if (hipMalloc((void **)&c->d_params, sizeof(DParams)) != hipSuccess || hipMalloc((void **)&c->d_t6, 768 * 4) != hipSuccess ||
-        hipMalloc((void **)&c->d_t5, 192 * 4) != hipSuccess || hipMalloc((void **)&c->d_t4, 48 * 4) != hipSuccess ||
-        hipMalloc((void **)&c->d_t3, 12 * 4) != hipSuccess) { c->err = "hipMalloc failed"; return fail(PHX_E_NOMEM); }
-    if (hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t6, c6.data(), 768 * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_t5, c5.data(), 192 * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_t4, c4.data(), 48 * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(c->d_t3, c3.data(), 12 * 4, hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(PHX_E_HIP); }
+    if (hipMalloc((void **)&c->d_params, sizeof(DParams)) != hipSuccess) { c->err = "hipMalloc failed"; return fail(PHX_E_NOMEM); }
+    if (hipMemcpy(c->d_params, &dp, sizeof(dp), hipMemcpyHostToDevice) != hipSuccess) { c->err = "hipMemcpy failed"; return fail(PHX_E_HIP); }
     *out = c;
     return PHX_OK;
 }
@@ -689,17 +630,13 @@ void phx_destroy(phx_ctx *c) {
     (void)hipSetDevice(c->device);
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_ascii, &c->b_meta, &c->b_tiles, &c->b_rbs, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
+    DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_recs, &c->b_meta, &c->b_tiles, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
                      &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->h_tot) (void)hipHostFree(c->h_tot);
     if (c->d_params) (void)hipFree(c->d_params);
-    if (c->d_t6) (void)hipFree(c->d_t6);
-    if (c->d_t5) (void)hipFree(c->d_t5);
-    if (c->d_t4) (void)hipFree(c->d_t4);
-    if (c->d_t3) (void)hipFree(c->d_t3);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_genes) (void)hipHostFree(c->h_genes);
     c->meta.release();
@@ -739,13 +676,13 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     if (c->in_flight) (void)settle(c); // a run still in flight reads the buffers this call replaces
     if (c->upload_pending) { HIPCHK(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; } // the previous batch's copies read the staging memory
     c->attached = nullptr;
-    c->packed = true;
     int rc = set_batch_layout(c, n, len, nullptr);
     if (rc) return rc;
-    // The letters cross the link as nibbles (phx_pack_bases: base code, "not acgt", "outside the alphabet"; rows stay 16-base aligned,
-    // so a row starts at byte off / 2): the staging pass has to touch every letter anyway and writes — and PCIe moves — half the bytes.
-    const size_t T = ((size_t)c->totalL + 1) / 2 + 64;
-    if ((rc = ensure(c, c->b_ascii, T))) return rc;
+    // The letters cross the link as the records the kernels read (phx_pack_planes: residue-split bit planes, 36 bytes per 96 bases; the
+    // records of a contig are followed by its all-outside spacer; records 0 and vtotal + 1 are pads): the staging pass has to touch
+    // every letter anyway and writes — and PCIe moves — three bits per base.
+    const size_t T = ((size_t)c->vtotal + 2) * 36;
+    if ((rc = ensure(c, c->b_recs, T))) return rc;
     if (c->h_stage_cap < T) {
         if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
         c->h_stage = nullptr; c->h_stage_cap = 0;
@@ -754,14 +691,13 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     }
     // Packed into pinned memory and sent in pieces of >= 4 Mbases (whole contigs; 2 MB copies reach ~45 of the link's 56 GB/s), so
     // that the DMA of one piece overlaps the packing of the next.  Large batches are packed by the context's worker threads, all of
-    // them on the earliest unfinished piece (items of <= 128 Kbases, taken in order), so that the first copy starts after 1/threads
+    // them on the earliest unfinished piece (items of <= 96 Kbases, taken in order), so that the first copy starts after 1/threads
     // of a piece's packing time; the calling thread enqueues each piece as soon as its last item is done.
     StageTimer t(c, ST_COPY);
     // k_features needs nothing but the bases: it is launched piece by piece behind the copies, on a side stream, so that the link and
     // the kernel work side by side and the run that follows starts at the ORF scan.  (The accumulators it adds to are reset here, as
     // the head of a run does; a run that is repeated on this batch — or retried with other buffer sizes — does all of it again.)
-    bool eager = c->n > 0 && !c->tiles.empty() && c->aux[1] && !c->one_stream && !c->prof;
-    std::vector<int> tile_first;
+    bool eager = c->n > 0 && c->vtotal > 0 && c->aux[1] && !c->one_stream && !c->prof;
     DBatch fb;
     if (eager) {
         if ((rc = ensure_position_buffers(c))) return rc;
@@ -774,37 +710,39 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s0));
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)c->n, hipMemcpyDeviceToDevice, s0));
         fill_batch(c, &fb);
-        tile_first.assign((size_t)n + 1, (int)c->tiles.size());
-        for (int k = (int)c->tiles.size() - 1; k >= 0; k--) tile_first[(size_t)c->tiles[(size_t)k].contig] = k; // tiles are in contig order
-        for (int i = n - 1; i >= 0; i--) if (tile_first[(size_t)i] > tile_first[(size_t)i + 1]) tile_first[(size_t)i] = tile_first[(size_t)i + 1]; // (a contig without tiles)
     }
     int n_sent = 0;
-    struct Piece { int i0, i1; int64_t beg, end; int items; };
-    struct Item { const char *in; int64_t n; uint8_t *out; int piece; };
+    struct Piece { int i0, i1; int64_t r0, r1; int items; };              // contigs [i0, i1) = records [r0, r1)
+    struct Item { const char *in; int64_t n; uint32_t *out; int64_t nrec; int piece; };
     std::vector<Piece> pieces;
     std::vector<Item> items;
+    uint32_t *stage = (uint32_t *)c->h_stage;
     {
-        const int64_t piece = PHX_UPLOAD_PIECE, chunk = 128 << 10;
-        int64_t sent = 0; int first = 0;
+        const int64_t piece = PHX_UPLOAD_PIECE / 96, chunk = 96 * 1024; // (records; letters)
+        int64_t sent = 0; int first = 0; // record 0, the pad, goes with the first piece
         for (int i = 0; i < n; i++) {
-            const int64_t end = i + 1 < n ? c->meta[(size_t)i + 1].off : c->totalL; // rows are 16-base aligned: the gap belongs to the piece
-            uint8_t *row = (uint8_t *)c->h_stage + (c->meta[(size_t)i].off >> 1);
-            for (int64_t o = 0; o < len[i]; o += chunk) items.push_back(Item{seq[i] + o, std::min(chunk, len[i] - o), row + (o >> 1), (int)pieces.size()});
+            const int64_t r0 = c->meta[(size_t)i].rec_off, nrec = 2 * (int64_t)c->meta[(size_t)i].nw + 1;
+            const int64_t end = i + 1 < n ? r0 + nrec : (int64_t)c->vtotal + 2; // (the pad behind the last record goes with the last piece)
+            for (int64_t o = 0; o < len[i] || o == 0; o += chunk) {
+                const bool last = o + chunk >= len[i];
+                items.push_back(Item{seq[i] + o, std::min(chunk, len[i] - o), stage + (size_t)(r0 + o / 96) * 9, last ? nrec - o / 96 : chunk / 96, (int)pieces.size()});
+            }
             if (end - sent >= piece || i + 1 == n) {
                 int cnt = 0;
                 for (size_t k = items.size(); k > 0 && items[k - 1].piece == (int)pieces.size(); k--) cnt++;
                 pieces.push_back(Piece{first, i + 1, sent, end, cnt}); sent = end; first = i + 1;
             }
         }
+        for (int k = 0; k < 9; k++) { stage[k] = k % 3 == 2 ? ~0u : 0u; stage[((size_t)c->vtotal + 1) * 9 + (size_t)k] = stage[k]; } // the two pads
     }
-    auto send_piece = [&](const Piece &pc) { // [beg, end) in bases -> bytes (piece boundaries are row starts: even)
-        const size_t b0 = (size_t)(pc.beg >> 1), b1 = (size_t)((pc.end + 1) >> 1);
-        hipError_t e = hipMemcpyAsync((char *)c->b_ascii.p + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess && eager) { // this piece's tiles, as soon as its bases have landed
+    auto send_piece = [&](const Piece &pc) {
+        const size_t b0 = (size_t)pc.r0 * 36, b1 = (size_t)pc.r1 * 36;
+        hipError_t e = hipMemcpyAsync((char *)c->b_recs.p + b0, (char *)c->h_stage + b0, b1 - b0, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && eager) { // this piece's records, as soon as its bases have landed
             hipEvent_t ev = c->ev_piece[n_sent & 1];
-            const int t0 = tile_first[(size_t)pc.i0], t1 = tile_first[(size_t)pc.i1];
-            if ((e = hipEventRecord(ev, c->stream)) == hipSuccess && (e = hipStreamWaitEvent(c->aux[1], ev, 0)) == hipSuccess && t1 > t0)
-                phxk_features(&fb, (const DTile *)c->b_tiles.p + t0, t1 - t0, c->aux[1]);
+            const uint32_t v0 = c->ftab[(size_t)pc.i0], v1 = c->ftab[(size_t)pc.i1];
+            if ((e = hipEventRecord(ev, c->stream)) == hipSuccess && (e = hipStreamWaitEvent(c->aux[1], ev, 0)) == hipSuccess && v1 > v0)
+                phxk_features(&fb, v0, v1, c->aux[1]);
         }
         n_sent++;
         return e;
@@ -821,7 +759,7 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
     if (nthreads == 0) {
         int k = 0;
         for (const Piece &pc : pieces) {
-            for (int e = k + pc.items; k < e; k++) phx_pack_bases(items[(size_t)k].in, items[(size_t)k].n, items[(size_t)k].out);
+            for (int e = k + pc.items; k < e; k++) phx_pack_planes(items[(size_t)k].in, items[(size_t)k].n, items[(size_t)k].out, items[(size_t)k].nrec);
             HIPCHK(c, send_piece(pc));
         }
     } else {
@@ -831,7 +769,7 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         const std::function<void()> work = [&]() {
             for (int k; (k = next.fetch_add(1)) < ni;) {
                 const Item &it = items[(size_t)k];
-                phx_pack_bases(it.in, it.n, it.out);
+                phx_pack_planes(it.in, it.n, it.out, it.nrec);
                 left[(size_t)it.piece].fetch_sub(1, std::memory_order_acq_rel);
             }
         };
@@ -930,8 +868,7 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
     if (c->in_flight) (void)settle(c);
     int rc = set_batch_layout(c, n, nullptr, offsets);
     if (rc) return rc;
-    c->attached = d_ascii;
-    c->packed = false; // the caller's letters as they are
+    c->attached = d_ascii; // the caller's letters as they are: the head of every run turns them into records (k_pack_planes)
     c->uploaded = true;
     return PHX_OK;
 }
@@ -971,7 +908,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToDevice, s)); // accumulators back to zero
     }
     fill_batch(c, &b);
-    if (!head_done) { StageTimer t(c, ST_FEATURES); phxk_features(&b, (const DTile *)c->b_tiles.p, (int)c->tiles.size(), s); }
+    if (!head_done) {
+        StageTimer t(c, ST_FEATURES);
+        if (c->attached) phxk_pack_planes(&b, c->attached, s);
+        phxk_features(&b, 0u, c->vtotal, s);
+    }
     // word-prefix popcounts of the bitmaps (for k_orf_stats) on a side stream, beside the ORF scan
     HIPCHK(c, hipEventRecord(c->ev_fork_pre, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_pre, 0));
@@ -1144,7 +1085,7 @@ int push_layout(phx_ctx *c) {
         for (DMeta &m : c->meta) {
             DMeta k = m;
             memset(&m, 0, sizeof(m));
-            m.off = k.off; m.L = k.L; m.nw = k.nw; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
+            m.off = k.off; m.L = k.L; m.nw = k.nw; m.rec_off = k.rec_off; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
             m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
             m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
             if ((k.status == PHX_S_PARALLEL || k.status == PHX_S_BADTRNA) && k.n_tedge < 0) { m.status = k.status; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74); a hit outside the contig
@@ -1153,14 +1094,14 @@ int push_layout(phx_ctx *c) {
         c->meta0_dirty = false; pushed = true;
     }
     if (c->tiles_dirty) { // once per batch layout
-        const size_t tb = sizeof(DTile) * c->tiles.size();
+        const size_t tb = 4 * c->ftab.size();
         if (c->h_tiles_cap < tb) {
             if (c->h_tiles) HIPCHK(c, hipHostFree(c->h_tiles));
             c->h_tiles = nullptr; c->h_tiles_cap = 0;
             HIPCHK(c, hipHostMalloc(&c->h_tiles, tb + tb / 4 + 4096, hipHostMallocDefault));
             c->h_tiles_cap = tb + tb / 4 + 4096;
         }
-        if (tb) { memcpy(c->h_tiles, c->tiles.data(), tb); HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->h_tiles, tb, hipMemcpyHostToDevice, s)); }
+        if (tb) { memcpy(c->h_tiles, c->ftab.data(), tb); HIPCHK(c, hipMemcpyAsync(c->b_tiles.p, c->h_tiles, tb, hipMemcpyHostToDevice, s)); }
         c->tiles_dirty = false; pushed = true;
     }
     if (pushed) { HIPCHK(c, hipEventRecord(c->ev_layout, s)); c->layout_pending = true; }
@@ -1630,26 +1571,35 @@ int phx_tap_globals(phx_ctx *c, int32_t contig, phx_globals *out) {
     return PHX_OK;
 }
 
+// the bases of a contig as codes (0 a, 1 c, 2 t, 3 g, 4 anything else), from the records the kernels read
+static int fetch_codes(phx_ctx *c, const DMeta &m, std::vector<uint8_t> &codes) {
+    const size_t L = (size_t)m.L, nrec = 2 * (size_t)m.nw;
+    codes.assign(L, 4);
+    if (!L) return PHX_OK;
+    std::vector<uint32_t> rec(nrec * 9);
+    HIPCHK(c, hipMemcpy(rec.data(), (const uint32_t *)c->b_recs.p + (size_t)m.rec_off * 9, rec.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < L; p++) {
+        const size_t r = p % 3, k = p / 3;
+        const uint32_t *q = &rec[(k >> 5) * 9 + r * 3];
+        const unsigned sh = (unsigned)(k & 31);
+        codes[p] = ((q[2] >> sh) & 1u) ? (uint8_t)4 : (uint8_t)(((q[0] >> sh) & 1u) | (((q[1] >> sh) & 1u) << 1));
+    }
+    return PHX_OK;
+}
+
 int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, uint8_t *binF, uint8_t *binR) {
     TAP_PRE(c, contig);
     const size_t L = (size_t)m.L;
-    if (cls) { // the device keeps the codon classes as four bitmaps and the start-codon index in the RBS word; the "rev_comp(codon) is a
-               // start" bit of a forward start codon (no kernel reads it) comes from the letters
+    if (cls) { // the device keeps the codon classes as four bitmaps; the start-codon index and the "rev_comp(codon) is a start" bit of a
+               // forward start codon (no kernel keeps them per position) come from the bases and the class table
         const size_t nw = (size_t)m.nw;
         std::vector<uint64_t> bits((size_t)4 * 3 * nw);
-        std::vector<uint16_t> r(L);
-        std::vector<uint8_t> asc(L);
+        std::vector<uint8_t> cd;
         if (nw) HIPCHK(c, hipMemcpy(bits.data(), (uint64_t *)c->b_bits.p + m.bits_off, bits.size() * 8, hipMemcpyDeviceToHost));
-        if (L) HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));
-        if (L && !c->packed) HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
-        if (L && c->packed) { // nibbles: back to a letter per position (what is not one of acgt reads as 'n' here)
-            std::vector<uint8_t> pk((L + 1) / 2);
-            HIPCHK(c, hipMemcpy(pk.data(), (const uint8_t *)c->b_ascii.p + (m.off >> 1), pk.size(), hipMemcpyDeviceToHost));
-            for (size_t p = 0; p < L; p++) { const unsigned nb = (pk[p >> 1] >> (4 * (p & 1))) & 15u; asc[p] = (nb & 4u) ? (uint8_t)'n' : (uint8_t)"actg"[nb & 3u]; }
-        }
+        int rc = fetch_codes(c, m, cd);
+        if (rc) return rc;
         DParams dp;
         build_dparams(&c->params, &dp);
-        auto code = [](uint8_t ch) -> int { switch (ch | 0x20) { case 'a': return 0; case 'c': return 1; case 't': return 2; case 'g': return 3; default: return -1; } };
         for (size_t p = 0; p < L; p++) {
             uint8_t v = 0;
             if (p + 3 <= L) {
@@ -1657,9 +1607,11 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
                 auto bit = [&](int id) { return (int)((bits[((size_t)id * 3 + f) * nw + (k >> 6)] >> (k & 63)) & 1ull); };
                 const int cl = bit(0) ? CLS_FS : bit(1) ? CLS_RS : bit(2) ? CLS_FT : bit(3) ? CLS_RT : CLS_NONE;
                 v = (uint8_t)cl;
-                if (cl == CLS_FS || cl == CLS_RS) v |= (uint8_t)((r[p] >> 12) << 3);
-                const int c0 = code(asc[p]), c1 = code(asc[p + 1]), c2 = code(asc[p + 2]);
-                if (c0 >= 0 && c1 >= 0 && c2 >= 0) v |= (uint8_t)(dp.cls_tab[c0 | (c1 << 2) | (c2 << 4)] & 0x80u);
+                if (cd[p] < 4 && cd[p + 1] < 4 && cd[p + 2] < 4) {
+                    const uint8_t t = dp.cls_tab[cd[p] | (cd[p + 1] << 2) | (cd[p + 2] << 4)];
+                    if (cl == CLS_FS || cl == CLS_RS) v |= (uint8_t)(t & 0x78u);
+                    v |= (uint8_t)(t & 0x80u);
+                }
             }
             cls[p] = v;
         }
@@ -1681,10 +1633,30 @@ int phx_tap_positions(phx_ctx *c, int32_t contig, uint8_t *cls, uint8_t *gcc, ui
             gcc[p] = g;
         }
     }
-    if (binF || binR) {
-        std::vector<uint16_t> r(L);
-        HIPCHK(c, hipMemcpy(r.data(), (uint16_t *)c->b_rbs.p + m.off, L * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < L; i++) { if (binF) binF[i] = (uint8_t)(r[i] & 31u); if (binR) binR[i] = (uint8_t)((r[i] >> 5) & 31u); }
+    if (binF || binR) { // the RBS bins of every window are no output of a run any more: k_features computes them once more for this
+                        // contig and leaves them as bit planes ([record][strand][stream][bit], the same code as the run's)
+        const size_t nrec = 2 * (size_t)m.nw;
+        std::vector<uint32_t> tp(nrec * 30);
+        if (nrec) {
+            uint32_t *d = nullptr;
+            HIPCHK(c, hipMalloc((void **)&d, tp.size() * 4));
+            DBatch b;
+            fill_batch(c, &b);
+            const uint32_t v0 = c->ftab[(size_t)contig];
+            phxk_features_tap(&b, contig, v0, v0 + (uint32_t)nrec, d, c->stream);
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipMemcpy(tp.data(), d, tp.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            HIPCHK(c, e);
+        }
+        for (size_t p = 0; p < L; p++) {
+            const size_t r = p % 3, k = p / 3, w = k >> 5;
+            const unsigned sh = (unsigned)(k & 31);
+            unsigned f = 0, rv = 0;
+            for (int bb = 0; bb < 5; bb++) { f |= ((tp[((w * 2 + 0) * 3 + r) * 5 + bb] >> sh) & 1u) << bb; rv |= ((tp[((w * 2 + 1) * 3 + r) * 5 + bb] >> sh) & 1u) << bb; }
+            if (binF) binF[p] = (uint8_t)f;
+            if (binR) binR[p] = (uint8_t)rv;
+        }
     }
     return PHX_OK;
 }
@@ -1903,17 +1875,7 @@ static int exact_fetch(phx_ctx *c, int32_t contig, ExactIn &in) {
     const DMeta &m = c->meta[(size_t)contig];
     in.ewi.resize(in.ed.size());
     if (!in.ewi.empty()) HIPCHK(c, hipMemcpy(in.ewi.data(), (long long *)c->b_ew.p + m.edge_off, in.ewi.size() * 8, hipMemcpyDeviceToHost));
-    const size_t L = (size_t)in.L;
-    if (L && c->packed) {
-        std::vector<uint8_t> pk((L + 1) / 2);
-        HIPCHK(c, hipMemcpy(pk.data(), (const uint8_t *)c->b_ascii.p + (m.off >> 1), pk.size(), hipMemcpyDeviceToHost));
-        static const uint8_t map4[4] = {0, 1, 2, 3}; // nibble code a0 c1 t2 g3
-        for (size_t p = 0; p < L; p++) { const unsigned nb = (pk[p >> 1] >> (4 * (p & 1))) & 15u; in.base[p] = (nb & 4u) ? (uint8_t)4 : map4[nb & 3u]; }
-    } else if (L) {
-        std::vector<uint8_t> asc(L);
-        HIPCHK(c, hipMemcpy(asc.data(), (const uint8_t *)(c->attached ? c->attached : c->b_ascii.p) + m.off, L, hipMemcpyDeviceToHost));
-        for (size_t p = 0; p < L; p++) { switch (asc[p] | 0x20) { case 'a': in.base[p] = 0; break; case 'c': in.base[p] = 1; break; case 't': in.base[p] = 2; break; case 'g': in.base[p] = 3; break; default: in.base[p] = 4; } }
-    }
+    if ((rc = fetch_codes(c, m, in.base))) return rc;
     return PHX_OK;
 }
 

@@ -332,49 +332,72 @@ int phx_format_tabular(int32_t n, const char *const *names, const phx_gene *gene
 
 void phx_free_text(char *text) { free(text); }
 
-/* ---- bases packed for the link (phx_upload): one nibble per letter, two per byte, low nibble first ----
- * bits 0-1 base code a0 c1 t2 g3 — for an ambiguity code the base the reference counts it as (s, b, v -> g; the others -> a,
- * functions.py:159-163) —, bit 2 = not one of acgt, bit 3 = a letter outside acgtnryswkmbvdh (KeyError in rev_comp,
- * functions.py:20-24); any case (functions.py:144).  k_features decodes the nibbles; half the bytes cross PCIe, and the staging
- * pass that has to touch every letter anyway writes half as much. */
-static const uint8_t kNib[32] = {12, 0, 7, 1, 4, 12, 12, 3, 4, 12, 12, 4, 12, 4, 4, 12, /* ` a b c d e f g h i j k l m n o */
-                                 12, 12, 4, 7, 2, 12, 7, 4, 12, 4, 12, 12, 12, 12, 12, 12}; /* p q r s t u v w x y z { | } ~ DEL */
-static inline uint8_t nib_of(uint8_t ch) {
+/* ---- bases packed for the link and for the kernels (phx_upload): residue-split bit planes ----
+ * Position p = 3 k + r of a contig: stream r, index k.  A record holds 32 indices of the three streams as nine 32-bit words
+ * [stream][b0, b1, amb] (36 bytes per 96 letters): b0, b1 = base code a0 c1 t2 g3 — for an ambiguity code the base the reference
+ * counts it as (s, b, v -> g; the others -> a, functions.py:159-163) —, amb = not one of acgt; a letter outside acgtnryswkmbvdh
+ * (KeyError in rev_comp, functions.py:20-24) is (0, 1, 1), a position outside the contig (0, 0, 1); any case (functions.py:144).
+ * This is the form k_features works in (phx_feat_core.h): 3 bits per base cross PCIe, and the staging pass that has to touch every
+ * letter anyway does the stride-3 split (pext) the kernels would otherwise pay for. */
+static const uint8_t kCode3[32] = {6, 0, 7, 1, 4, 6, 6, 3, 4, 6, 6, 4, 6, 4, 4, 6, /* ` a b c d e f g h i j k l m n o */
+                                   6, 6, 4, 7, 2, 6, 7, 4, 6, 4, 6, 6, 6, 6, 6, 6}; /* p q r s t u v w x y z { | } ~ DEL */
+static inline uint8_t code3_of(uint8_t ch) {
     const uint8_t x = (uint8_t)(ch | 0x20u);
-    return (x & 0xe0u) == 0x60u ? kNib[x & 31u] : (uint8_t)12; /* ('@' and '[' .. '_' land on entries that are not letters) */
+    return (x & 0xe0u) == 0x60u ? kCode3[x & 31u] : (uint8_t)6; /* ('@' and '[' .. '_' land on entries that are not letters) */
 }
-static void pack_scalar(const uint8_t *in, size_t n, uint8_t *out) {
-    size_t i = 0;
-    for (; i + 1 < n; i += 2) out[i >> 1] = (uint8_t)(nib_of(in[i]) | (nib_of(in[i + 1]) << 4));
-    if (i < n) out[i >> 1] = nib_of(in[i]);
+static inline void rec_outside(uint32_t *rec) { for (int i = 0; i < 9; i++) rec[i] = i % 3 == 2 ? ~0u : 0u; }
+/* one record from up to 96 letters (positions behind n: outside) */
+static void pack_rec_scalar(const uint8_t *in, size_t n, uint32_t *rec) {
+    rec_outside(rec);
+    if (n > 96) n = 96;
+    for (size_t p = 0; p < n; p++) {
+        const uint32_t cd = code3_of(in[p]), r = (uint32_t)(p % 3), k = (uint32_t)(p / 3);
+        uint32_t *q = rec + r * 3;
+        q[0] |= (cd & 1u) << k; q[1] |= ((cd >> 1) & 1u) << k;
+        if (!(cd & 4u)) q[2] &= ~(1u << k);
+    }
 }
 #if defined(__x86_64__)
-__attribute__((target("avx2"))) static void pack_avx2(const uint8_t *in, size_t n, uint8_t *out) {
-    const __m256i lut_lo = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)kNib));
-    const __m256i lut_hi = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)(kNib + 16)));
+__attribute__((target("avx2,bmi2"))) static size_t pack_avx2(const uint8_t *in, size_t n, uint32_t *out) { /* whole records only; returns the records written */
+    const __m256i lut_lo = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)kCode3));
+    const __m256i lut_hi = _mm256_broadcastsi128_si256(_mm_loadu_si128((const __m128i *)(kCode3 + 16)));
     const __m256i c20 = _mm256_set1_epi8(0x20), c1f = _mm256_set1_epi8(0x1f), ce0 = _mm256_set1_epi8((char)0xe0), c60 = _mm256_set1_epi8(0x60),
-                  c10 = _mm256_set1_epi8(0x10), cbad = _mm256_set1_epi8(12), cmul = _mm256_set1_epi16(0x1001);
-    size_t i = 0;
-    for (; i + 32 <= n; i += 32) {
-        const __m256i x = _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(in + i)), c20);
-        const __m256i v = _mm256_and_si256(x, c1f);
-        const __m256i lo = _mm256_shuffle_epi8(lut_lo, v), hi = _mm256_shuffle_epi8(lut_hi, v);
-        __m256i nb = _mm256_blendv_epi8(lo, hi, _mm256_cmpeq_epi8(_mm256_and_si256(v, c10), c10));
-        nb = _mm256_blendv_epi8(cbad, nb, _mm256_cmpeq_epi8(_mm256_and_si256(x, ce0), c60));
-        const __m256i w = _mm256_maddubs_epi16(nb, cmul);             /* per pair: even letter + 16 * odd letter */
-        const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(w, w), 0xd8);
-        _mm_storeu_si128((__m128i *)(out + (i >> 1)), _mm256_castsi256_si128(pk));
+                  c10 = _mm256_set1_epi8(0x10), cbad = _mm256_set1_epi8(6);
+    static const uint64_t M[3] = {0x9249249249249249ull, 0x2492492492492492ull, 0x4924924924924924ull}; /* letters 0..63 of stream r */
+    static const uint32_t N[3] = {0x24924924u, 0x49249249u, 0x92492492u};                                 /* letters 64..95 */
+    static const int CNT[3] = {22, 21, 21};
+    size_t nr = 0;
+    for (size_t i = 0; i + 96 <= n; i += 96, nr++) {
+        __m256i cd[3];
+        for (int j = 0; j < 3; j++) {
+            const __m256i x = _mm256_or_si256(_mm256_loadu_si256((const __m256i *)(in + i + 32 * j)), c20);
+            const __m256i v = _mm256_and_si256(x, c1f);
+            const __m256i lo = _mm256_shuffle_epi8(lut_lo, v), hi = _mm256_shuffle_epi8(lut_hi, v);
+            __m256i nb = _mm256_blendv_epi8(lo, hi, _mm256_cmpeq_epi8(_mm256_and_si256(v, c10), c10));
+            cd[j] = _mm256_blendv_epi8(cbad, nb, _mm256_cmpeq_epi8(_mm256_and_si256(x, ce0), c60));
+        }
+        uint32_t *rec = out + nr * 9;
+        for (int pl = 0; pl < 3; pl++) { /* bit `pl` of every code to bit 7 of its byte, then one mask bit per letter */
+            const uint64_t m0 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(cd[0], 7 - pl));
+            const uint64_t m1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(cd[1], 7 - pl));
+            const uint32_t m2 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(cd[2], 7 - pl));
+            const uint64_t lo64 = m0 | (m1 << 32);
+            for (int r = 0; r < 3; r++) rec[r * 3 + pl] = (uint32_t)_pext_u64(lo64, M[r]) | ((uint32_t)_pext_u64(m2, N[r]) << CNT[r]);
+        }
     }
-    if (i < n) pack_scalar(in + i, n - i, out + (i >> 1)); /* (i is even) */
+    return nr;
 }
 #endif
-/* n letters -> (n + 1) / 2 bytes */
-void phx_pack_bases(const char *in, int64_t n, uint8_t *out) {
-    if (n <= 0) return;
+/* n letters, the first of them at a position of its contig that is a multiple of 96 -> nrec records at `out`: ceil(n / 96) from the
+ * letters (positions behind n: outside), the rest all-outside (a contig's unused records and the spacer behind it) */
+void phx_pack_planes(const char *in, int64_t n, uint32_t *out, int64_t nrec) {
+    size_t done = 0;
+    if (n < 0) n = 0;
 #if defined(__x86_64__)
     static int have = -1;
-    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
-    if (have) { pack_avx2((const uint8_t *)in, (size_t)n, out); return; }
+    if (have < 0) have = (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2")) ? 1 : 0;
+    if (have && n >= 96) done = pack_avx2((const uint8_t *)in, (size_t)n, out);
 #endif
-    pack_scalar((const uint8_t *)in, (size_t)n, out);
+    for (; (int64_t)done < nrec && (int64_t)done * 96 < n; done++) pack_rec_scalar((const uint8_t *)in + done * 96, (size_t)n - done * 96, out + done * 9);
+    for (; (int64_t)done < nrec; done++) rec_outside(out + done * 9);
 }

@@ -1,7 +1,7 @@
 // phx_internal.h — device/host shared layouts of libphx (not part of the public ABI).
 //
 // Data layout in HBM (one batch = n contigs, concatenated):
-//   per position (index = meta.off + p, p 0-based):  ascii u8, rbs u16 (RBS bins, 'atg' flags, start-codon index); everything else
+//   per position:  the bases as residue-split bit planes (recs: 36-byte records of 96 positions, phx_features.inc); everything else
 //       that is a predicate of a position or codon lives in bitmaps (bits, nbits: DESIGN.md §3)
 //   per ORF   (index = meta.orf_off + k):  DOrf head (16 B), DOrfStat (32 B), weight f64, start-node id i32 — four arrays, each
 //       written whole by one kernel (k_orf<true>, k_orf_stats, k_score, k_node_build)
@@ -16,24 +16,14 @@
 
 #include "../../include/phx.h"
 
-#define PHX_TILE 1536       // positions per feature-kernel workgroup = 8 bitmap words (64 codons) per frame
-#define PHX_HALO 64         // >= 60 (GC window reach) and >= 20 (RBS window reach)
-#define PHX_FEAT_THREADS 256
+#define PHX_TILE 1536       // a contig's bitmaps cover whole tiles of this many positions = 8 bitmap words (64 codons) per frame
 #define PHX_CTG_THREADS 256 // per-contig workgroup kernels
 #define PHX_N_CODON_BITMAPS 12 // 0-3 fwd start, rev start, fwd stop, rev stop; 4-9 GC frame plot: the comparisons a > b, b > c, a > c of a codon's three window counts and c > b, b > a, c > a for the reversed triple (max_idx / min_idx follow, see gc_planes); 10-11 'atg' on the forward / reverse strand
 #define PHX_PLANE_GCF 4  // first of the three forward comparison planes
 #define PHX_PLANE_GCR 7  // ... of the reversed triple
 #define PHX_PLANE_ATG 10 // 'atg' forward, then reverse
 #define PHX_PRE_G 2 // bitmap words per prefix-popcount record (k_bit_prefix; a power of two <= 8: nw is a multiple of 8)
-#define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3 + 4 * 3) // codon bitmaps x 3 frames + 4 base bitmaps of 3*nw words
-
-// score_rbs (functions.py:48-138): every score 1..27 belongs to exactly one offset class, so a set of scores is a bit set and the
-// hits of the four classes share one word (k_features; checked against the rule list in phx_create_ex)
-#define RBS_CLS0 ((1u << 1) | (1u << 5) | (1u << 8) | (1u << 11) | (1u << 18) | (1u << 21) | (1u << 23) | (1u << 26))                  // offsets 3-4
-#define RBS_CLS1 ((1u << 9) | (1u << 13) | (1u << 14) | (1u << 15) | (1u << 16) | (1u << 19) | (1u << 22) | (1u << 24) | (1u << 27))   // offsets 5-10
-#define RBS_CLS2 ((1u << 4) | (1u << 6) | (1u << 7) | (1u << 12) | (1u << 17) | (1u << 20) | (1u << 25))                               // offsets 11-12
-#define RBS_CLS3 ((1u << 2) | (1u << 3) | (1u << 10))                                                                                   // offsets 13-15
-static_assert((RBS_CLS0 | RBS_CLS1 | RBS_CLS2 | RBS_CLS3) == 0x0ffffffeu && (RBS_CLS0 & RBS_CLS1) == 0 && ((RBS_CLS0 | RBS_CLS1) & RBS_CLS2) == 0 && ((RBS_CLS0 | RBS_CLS1 | RBS_CLS2) & RBS_CLS3) == 0, "every score in one class");
+#define PHX_BITMAP_WORDS_PER_NW (PHX_N_CODON_BITMAPS * 3) // codon bitmaps x 3 frames (the bases themselves: DBatch.recs)
 
 // codon classes, in the elif order of functions.py:198-215
 #define CLS_NONE 0
@@ -161,6 +151,7 @@ struct DMeta { // one per contig
     int32_t plan_prog; // DBatch.plan_stream: windows whose records k_wave_plan<2,0> has published (| WV_PLAN_DONE when it has finished; -1: it
                        // gave the contig up) — k_sssp_wave<2,0> runs beside the planner and consumes the windows as they appear
     int32_t pad_;
+    int64_t rec_off;   // first record of this contig in DBatch.recs (2 nw + 1 records: the last one is all "outside")
 };
 
 // What the host needs of a contig after every run (the full DMeta record, 0.5 KB, comes over only when a tap asks for it)
@@ -174,11 +165,6 @@ struct DRes {
 // (two integer-valued doubles), eps = 0 if err == 0, else floor(err) + 1; err = infinity: nothing is known (the contig is not certified)
 struct DERef {
     double d1, d2, err;
-};
-
-struct DTile {
-    int32_t contig;
-    int32_t p0;
 };
 
 struct DGene {
@@ -236,23 +222,23 @@ struct DBatch {
     int64_t *lpart;     // k_layout*_a -> _b: per workgroup of 256 contigs the four totals (batches beyond 1024 contigs)
     DCaps caps;
     const DParams *params;
-    const uint32_t *rbs_t6, *rbs_t5, *rbs_t4, *rbs_t3;
     // per position
-    const uint8_t *ascii; // the bases: one ASCII letter per position (phx_attach), or — packed != 0, phx_upload — one nibble per position, two per
-                          //   byte (low nibble first): bits 0-1 base code a0 c1 t2 g3 (for an ambiguity code the base it counts as, functions.py:159-163),
-                          //   bit 2 = not one of acgt, bit 3 = a letter outside the IUPAC alphabet; a contig's row starts at byte off / 2
-    int32_t packed;
-    uint16_t *rbs;
+    uint32_t *recs;       // the bases as residue-split bit planes: record 0 is a pad, contig i owns the records DMeta.rec_off .. rec_off + 2 nw, one
+                          //   more pad at the end (phx_features.inc; written by phx_upload's copies or by k_pack_planes)
+    const uint32_t *voff; // per contig (+ 1): its first record - 1 = its first "virtual word" (k_features' index space)
+    const uint32_t *wfirst; // per 62 virtual words: the contig of the first of them (k_features)
+    uint32_t vtotal;      // virtual words of the batch = records without the two pads
+    int32_t defcod;       // the codon tables are the reference's defaults (file_handling.py:51-53): k_features uses their formulas
     uint64_t *nbits;    // per contig 9*nw words: node bitmap (forward slot), node bitmap (reverse slot), coverage bitmap; zeroed every run
     uint32_t *nbase;    // per contig 3*nw words: node rank at the start of every 64-position word
     uint64_t *cbits;    // per contig 2*ncw words over node ids: close nodes of the forward strand (forward stops), of the reverse strand (reverse starts); written whole by k_node_order
-    uint64_t *bits;     // per contig: [12 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k), then [a,c,t,g][3*nw] base bitmaps
+    uint64_t *bits;     // per contig: [12 codon bitmaps][frame 0..2][nw] (bit k of frame f <-> position f+3k)
     int32_t *iprev;     // per (strand, frame, word): the last item in front of it whose word holds a stop codon, -1: none (k_orf<false> -> k_orf<true>)
     uint2 *item;        // per (strand, frame, word): exclusive ORF / group offsets of the stop events in that word
     const DTNode *tnode; // tRNA nodes / edges of the batch (null: none)
     const DTEdge *tedge;
     int32_t *tnid;      // per tRNA node: its device node id (k_node_build -> k_edges)
-    uint32_t *cpre, *bpre; // word-prefix popcounts of the GC-frame class bitmaps / of the base bitmaps (k_bit_prefix, phx_orf.inc)
+    uint32_t *cpre, *bpre; // prefix popcounts of the GC-frame class bitmaps (per PHX_PRE_G words) / of the bases (a, c, t, g per record) (k_bit_prefix, phx_orf.inc)
     uint64_t *tbits;    // per contig 12*nw words at 4/3 * nbits_off: node bitmaps of the tRNA nodes, planes (strand, type) = forward start, forward stop, reverse start, reverse stop; zeroed every run
     DBridge *bridge;    // per contig bridge_cap entries: the uncovered runs of functions.py:334 (k_node_rank -> k_edges)
     // per ORF / group
@@ -305,9 +291,11 @@ struct DBatch {
 #ifdef __cplusplus
 extern "C" {
 #endif
-void phx_pack_bases(const char *in, int64_t n, uint8_t *out); // phx_host.c: letters -> nibbles (DBatch.ascii with packed != 0)
+void phx_pack_planes(const char *in, int64_t n, uint32_t *out, int64_t nrec); // phx_host.c: letters -> records (DBatch.recs), `in` starts at a record boundary
 // kernel launchers (phx_kernels.hip); all asynchronous on `stream`
-void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream);
+void phxk_features(const DBatch *b, uint32_t v_begin, uint32_t v_end, void *stream); // the records [v_begin + 1, v_end + 1)
+void phxk_features_tap(const DBatch *b, int contig, uint32_t v_begin, uint32_t v_end, uint32_t *tapbuf, void *stream); // RBS bins of every window of one contig as bit planes: [record of the contig][strand][stream][bit]
+void phxk_pack_planes(const DBatch *b, const void *letters, void *stream);            // phx_attach: the caller's letters -> records
 void phxk_orf_count(const DBatch *b, void *stream);
 void phxk_orf_emit(const DBatch *b, void *stream);
 void phxk_bit_prefix(const DBatch *b, void *stream);

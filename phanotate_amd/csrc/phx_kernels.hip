@@ -180,11 +180,20 @@ static void launch_certify(const DBatch *b, int vcap, hipStream_t s) {
     hipLaunchKernelGGL(k_certify_wide<NL>, dim3(b->n_contig), dim3(CERT_T), 0, s, *b);
 }
 extern "C" {
-void phxk_features(const DBatch *b, const DTile *tiles, int n_tiles, void *stream) {
-#ifndef FEAT_GRID
-#define FEAT_GRID 8192 // workgroups that walk the tiles (grid-stride): 4 tiles each on the benchmark batch balance better than 16 (0.465 -> 0.45 ms), one or two per workgroup lose the prefetch (0.49)
-#endif
-    if (n_tiles > 0) hipLaunchKernelGGL(k_features, dim3(n_tiles < FEAT_GRID ? n_tiles : FEAT_GRID), dim3(PHX_FEAT_THREADS), 0, (hipStream_t)stream, *b, tiles, n_tiles);
+void phxk_features(const DBatch *b, uint32_t v_begin, uint32_t v_end, void *stream) {
+    if (v_end <= v_begin) return;
+    const unsigned g = (v_end - 1) / FEAT_SPAN - v_begin / FEAT_SPAN + 1;
+    if (b->defcod) hipLaunchKernelGGL((k_features<false, true>), dim3(g), dim3(64), 0, (hipStream_t)stream, *b, v_begin, v_end, (uint32_t *)nullptr, -1);
+    else hipLaunchKernelGGL((k_features<false, false>), dim3(g), dim3(64), 0, (hipStream_t)stream, *b, v_begin, v_end, (uint32_t *)nullptr, -1);
+}
+// (host copies of voff are the caller's: it passes the contig's range)
+void phxk_features_tap(const DBatch *b, int contig, uint32_t v_begin, uint32_t v_end, uint32_t *tapbuf, void *stream) {
+    if (v_end <= v_begin) return;
+    const unsigned g = (v_end - 1) / FEAT_SPAN - v_begin / FEAT_SPAN + 1;
+    hipLaunchKernelGGL((k_features<true, false>), dim3(g), dim3(64), 0, (hipStream_t)stream, *b, v_begin, v_end, tapbuf, contig);
+}
+void phxk_pack_planes(const DBatch *b, const void *letters, void *stream) {
+    if (b->n_contig > 0) hipLaunchKernelGGL(k_pack_planes, dim3(8, b->n_contig), dim3(64), 0, (hipStream_t)stream, *b, (const uint8_t *)letters);
 }
 // Workgroups per contig of the per-contig kernels: `full` for the benchmark's 50 kb contigs, fewer for batches of short contigs
 // (a 2 kb contig has ~100 nodes: four workgroups of 256 threads would leave three idle), by the batch's mean contig length.

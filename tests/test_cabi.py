@@ -85,41 +85,22 @@ def test_synth_generator_is_pinned():
     assert set(a) <= set(b"acgt")
 
 
-def test_rbs_motif_table_equals_reference_chain(oracle):
-    """The position kernel scores a 21-mer as max over (offset, k-mer) table hits; the reference is an
-    if/elif chain (functions.py:48-138).  Check the host-built tables against the oracle's chain."""
-    t6 = np.zeros(4096, np.uint32); t5 = np.zeros(1024, np.uint32); t4 = np.zeros(256, np.uint32); t3 = np.zeros(64, np.uint32)
-    _lib.lib().phx_rbs_table(*[t.ctypes.data_as(C.c_void_p) for t in (t6, t5, t4, t3)])
-    tabs = {6: t6, 5: t5, 4: t4, 3: t3}
-    code = {"a": 0, "c": 1, "t": 2, "g": 3}
-    cls_of = lambda o: 0 if o <= 4 else 1 if o <= 10 else 2 if o <= 12 else 3
-    rng = np.random.RandomState(3)
+def test_host_packer_writes_the_record_layout():
+    """phx_upload's staging pass (phx_pack_planes, phx_host.c: AVX2 + pext, scalar tail) against the numpy statement of the layout the
+    kernels read (tests/test_feat_core_host.py::pack_records): residue-split bit planes, 36 bytes per 96 bases."""
+    from test_feat_core_host import pack_records
 
-    def table_score(seq):
-        s = seq[::-1]
-        best = 0
-        for o in range(3, 16):
-            v = min(6, len(s) - o)
-            if v < 3:
-                break
-            kc = sum(code[s[o + k]] << (2 * k) for k in range(v))
-            best = max(best, (int(tabs[v][kc]) >> (8 * cls_of(o))) & 0xFF)
-        return best
-
-    seen = set()
-    for it in range(6000):
-        n = 21 if it % 4 else rng.randint(1, 22)
-        if it % 3 == 0:  # plant a purine-rich core so that high bins are exercised
-            core = "".join(rng.choice(list("ag"), rng.randint(3, 9), p=[0.35, 0.65]))
-            pad = "".join(rng.choice(list("acgt"), 21))
-            k = rng.randint(0, 15)
-            seq = (pad[:k] + core + pad)[:n]
-        else:
-            seq = "".join(rng.choice(list("acgt"), n))
-        want = oracle.score_rbs(seq)
-        assert table_score(seq) == want, seq
-        seen.add(want)
-    assert len(seen) >= 20, "test windows reached only bins %s" % sorted(seen)
+    L_ = _lib.lib()
+    L_.phx_pack_planes.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+    L_.phx_pack_planes.restype = None
+    rnd = np.random.RandomState(9)
+    for n in (0, 1, 2, 3, 95, 96, 97, 191, 192, 1000, 96 * 40, 96 * 40 + 17, 12345):
+        seq = bytes(rnd.choice(list(b"acgtACGTnryswkmbvdhNRSxX-"), n, p=[0.2] * 4 + [0.02] * 4 + [0.12 / 17] * 17).astype(np.uint8))
+        nrec = (n + 95) // 96 + 2
+        got = np.full((nrec, 3, 3), 0xDEADBEEF, np.uint32)
+        L_.phx_pack_planes(seq, n, got.ctypes.data, nrec)
+        want = pack_records(seq, nrec)[1:-1]
+        assert np.array_equal(got, want), n
 
 
 def test_partition_is_balanced_and_complete():

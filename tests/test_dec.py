@@ -205,7 +205,7 @@ def test_number_text_does_not_follow_the_host_locale(ev):
         from phanotate_amd._lib import phx_params  # noqa: F401
 
         p = phx_params()
-        assert L.phx_params_from_flags(C.byref(p), 90, b"atg:0.85,gtg:0.10,ttg:0.05", b"tag,tga,taa") == 0
+        assert L.phx_params_from_flags(b"atg:0.85,gtg:0.10,ttg:0.05", b"tag,tga,taa", 90, C.byref(p)) == 0
         assert abs(p.start_w[1] - 0.10 / 0.85) < 1e-15
     finally:
         locale.setlocale(locale.LC_NUMERIC, old)
