@@ -182,7 +182,9 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_SIZE_EVERY_RUN 4u
 #define PHX_CREATE_SOLVER_GLOBAL 8u
 #define PHX_CREATE_SOLVER_NO_WAVE 16u
-/* NO_CERTIFY: phx_certified reports -1 (and the kernel's scratch, 20 + 32 bytes per node, is not allocated).
+/* NO_CERTIFY: phx_certified reports -1 (and the kernel's scratch, 20 + 32 bytes per node, is not allocated).  It also turns the
+ * exactness machinery off as a whole — without a certificate nothing says which contigs would need the host re-solve —: the gene lists
+ * of phx_download* are then the fp64-derived integers' shortest paths, WITHOUT the guarantee that they are the reference's.
  * CERT_TIGHT multiplies its error bounds by 2^36, so that ordinary inputs come out uncertified (tests of the host re-solve). */
 #define PHX_CREATE_NO_CERTIFY 32u
 #define PHX_CREATE_CERT_TIGHT 64u
@@ -303,6 +305,12 @@ int phx_set_profiling_stages(phx_ctx *ctx, uint32_t stage_mask);
    stream BESIDE stage 8, "edges_fill": it is in the table, not in the sum of the main stream's stages.) */
 int phx_get_stage_ms(phx_ctx *ctx, float *ms /* [PHX_N_STAGES] */, int32_t *launches /* [PHX_N_STAGES] */, int reset);
 const char *phx_stage_name(int k);
+/* Contigs, over the life of the context, whose shortest-path wavefront was launched beside the planner of its windows (batches of up to
+ * 3/4 of the device's SIMDs: DESIGN.md §4), saw no progress from it for ~20 ms and handed the contig to the workgroup kernel instead
+ * (phx_globals.sssp_handed_back == 5; the results are the same).  That only happens when the planner's wavefronts were not resident
+ * beside the solver's — other contexts or processes holding the SIMDs —, and after the first such run the context launches the solver
+ * behind its planner.  0 on an undisturbed GPU. */
+int64_t phx_plan_timeouts(phx_ctx *ctx);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
 int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
 

@@ -372,6 +372,11 @@ class Annotator:
         self._chk(self.L.phx_get_stage_ms(self.h, ms, nl, 1 if reset else 0), "phx_get_stage_ms")
         return {self.L.phx_stage_name(k).decode(): (float(ms[k]), int(nl[k])) for k in range(_lib.N_STAGES)}
 
+    def plan_timeouts(self):
+        """Contigs, over the life of the context, whose shortest-path wavefront gave up waiting for the planner it was launched beside
+        (include/phx.h: phx_plan_timeouts): 0 unless other contexts / processes kept the planner's wavefronts off the device."""
+        return int(self.L.phx_plan_timeouts(self.h))
+
     def batch_sizes(self):
         v = [C.c_int64() for _ in range(4)]
         self._chk(self.L.phx_batch_sizes(self.h, *[C.byref(x) for x in v]), "phx_batch_sizes")

@@ -191,6 +191,8 @@ struct phx_ctx {
     int n_simd = 1024; // SIMDs of the device (4 per CU): places of k_sssp_wave
     bool force_global_sssp = false; // development switch: run every contig through the global-memory SSSP kernel
     bool no_wave = false, always_sync = false;
+    int64_t plan_timeouts = 0;     // contigs, over the life of the context, whose solver gave up waiting for the planner it follows (phx_plan_timeouts)
+    bool plan_stream_off = false;  // ... after the first of them the solver is launched behind its planner again on this context
     float stage_ms[PHX_N_STAGES] = {0};
     int stage_n[PHX_N_STAGES] = {0};
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -986,7 +988,9 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // Which class follows its planner: the 128-bit contigs' tight configuration whenever the batch has such contigs; a batch that is ALL
     // 256-bit or all 512-bit contigs (a lone genome with a 2000+ codon ORF) streams that class's pair instead.
     int stream_k = -1;
-    if (c->n <= PHX_PLAN_STREAM_MAX && !b.sord && !c->one_stream && c->aux[3]) {
+    // (safe while every planner wavefront is resident beside the edge fill: bounded by the device's SIMD count, not by a constant;
+    //  and a context that has seen one time-out — another context or process held the SIMDs — goes back to waiting for the planner)
+    if (c->n <= std::min(PHX_PLAN_STREAM_MAX, c->n_simd * 3 / 4) && !c->plan_stream_off && !b.sord && !c->one_stream && c->aux[3]) {
         if ((mask >> 2) & 1) stream_k = 0;
         else for (int k = 1; k <= 2; k++) if (((mask >> (4 * k + 2)) & 1) && !(mask & 0xffff & ~(15 << (4 * k)))) stream_k = k;
     }
@@ -1176,6 +1180,7 @@ int finish_once(phx_ctx *c) {
     memcpy(c->h_tot, (const void *)(c->res + (size_t)c->n), sizeof(DTotals)); // the totals came with the per-contig records
     const DTotals *ht = c->h_tot;
     c->tie_seen = std::max(c->tie_seen, ht->tie_need);
+    if (ht->plan_timeouts > 0) { c->plan_timeouts += ht->plan_timeouts; c->plan_stream_off = true; c->graph_valid = false; } // (the results stand: the workgroup kernel solved those contigs)
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = ((ht->class_mask & ~mask) & 0xffff) == 0; // (bits 16+: which classes have contigs for the side launch of the workgroup kernel: a matter of speed only)
     for (int k = 0; k < 4; k++) covered = covered && ht->lds_need[k] <= lds[k];
@@ -1375,8 +1380,10 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
     return PHX_OK;
 }
 
-// The certificate is computed when it is first asked for after a run (k_certify on the state the run left on the device: distances,
-// parent edges, path, edge records), not inside phx_run: a caller that only wants gene lists at full rate does not pay for it.
+// The certificate is computed when it is first asked for after a run (k_refine + k_certify on the state the run left on the device:
+// distances, parent edges, path, edge records), not inside phx_run.  phx_download* ask for it (their gene lists are the reference's);
+// a caller that only wants the device's lists at full rate creates the context with PHX_CREATE_NO_EXACT (or phx_set_exact(ctx, 0)):
+// the downloads then skip it, phx_certified still computes it on demand.
 static int ensure_cert(phx_ctx *c) {
     if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1446,46 +1453,89 @@ int phx_pool_annotate(phx_pool *p, int32_t n, const char *const *seq, const int6
     if (n == 0) return PHX_OK;
     for (int i = 0; i < n; i++) { out[i].status = 0; out[i].n_genes = 0; out[i].genes = nullptr; }
     const size_t nl = p->lanes.size();
-    // consecutive batches of at most batch_bases bases; with several lanes at least two per lane, so that every GPU has two in flight
+    // the contigs are dealt to the lanes (GPUs) greedily, longest first, by the bases a lane already holds — one T4
+    // among two hundred phiX-sized contigs does not leave the other lanes idle —; inside a lane they keep their input order and are
+    // cut into batches of at most batch_bases bases, at least two per lane, so that every GPU has two in flight.
     int64_t total = 0;
     for (int i = 0; i < n; i++) total += len[i] > 0 ? len[i] : 0;
     int64_t limit = batch_bases > 0 ? batch_bases : 400000000ll;
     if (nl > 1) limit = std::max<int64_t>(1, std::min<int64_t>(limit, (total + 2 * (int64_t)nl - 1) / (2 * (int64_t)nl)));
-    std::vector<std::pair<int, int>> cuts; // [lo, hi)
-    for (int lo = 0; lo < n;) {
-        int hi = lo; int64_t size = 0;
-        while (hi < n && (hi == lo || size + len[hi] <= limit)) { size += len[hi]; hi++; }
-        cuts.push_back({lo, hi});
-        lo = hi;
-    }
+    std::vector<std::vector<int>> lane_idx(nl);
+    std::vector<std::vector<std::pair<int, int>>> lane_cuts(nl); // per lane: [lo, hi) into lane_idx
+    try {
+        if (nl == 1) { lane_idx[0].resize((size_t)n); for (int i = 0; i < n; i++) lane_idx[0][(size_t)i] = i; }
+        else {
+            std::vector<int> order((size_t)n);
+            for (int i = 0; i < n; i++) order[(size_t)i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+            std::vector<int64_t> load(nl, 0);
+            for (int i : order) {
+                size_t best = 0;
+                for (size_t j = 1; j < nl; j++) if (load[j] < load[best]) best = j;
+                lane_idx[best].push_back(i);
+                load[best] += len[i] > 0 ? len[i] : 0;
+            }
+            for (auto &v : lane_idx) std::sort(v.begin(), v.end());
+        }
+        for (size_t j = 0; j < nl; j++) {
+            const std::vector<int> &v = lane_idx[j];
+            for (size_t lo = 0; lo < v.size();) {
+                size_t hi = lo; int64_t size = 0;
+                while (hi < v.size() && (hi == lo || size + len[v[hi]] <= limit)) { size += len[v[hi]]; hi++; }
+                lane_cuts[j].push_back({(int)lo, (int)hi});
+                lo = hi;
+            }
+        }
+    } catch (const std::bad_alloc &) { p->err = "out of memory"; return PHX_E_NOMEM; }
     std::atomic<int> first_err{0};
     std::mutex em;
-    auto lane_work = [&](size_t j) {
+    auto lane_body = [&](size_t j) {
         phx_pool::Lane &ln = p->lanes[j];
-        std::vector<size_t> mine;
-        for (size_t k = j; k < cuts.size(); k += nl) mine.push_back(k);
-        auto fail = [&](int rc, phx_ctx *c) { int z = 0; if (first_err.compare_exchange_strong(z, rc)) { std::lock_guard<std::mutex> g(em); p->err = phx_last_error(c); } };
-        auto collect = [&](size_t t) { // batch mine[t] ran on ctx[t & 1]
+        const std::vector<int> &idx = lane_idx[j];
+        const std::vector<std::pair<int, int>> &cuts = lane_cuts[j];
+        auto fail = [&](int rc, phx_ctx *c) { int z = 0; if (first_err.compare_exchange_strong(z, rc)) { std::lock_guard<std::mutex> g(em); p->err = c ? phx_last_error(c) : "out of memory"; } };
+        std::vector<phx_result> tmp;
+        auto collect = [&](size_t t) { // batch t ran on ctx[t & 1]; its results go to their contigs' places
             phx_ctx *c = ln.ctx[t & 1];
-            const int rc = phx_download(c, out + cuts[mine[t]].first);
-            if (rc) fail(rc, c);
+            const int lo = cuts[t].first, hi = cuts[t].second;
+            tmp.assign((size_t)(hi - lo), phx_result{0, 0, nullptr});
+            const int rc = phx_download(c, tmp.data());
+            if (rc) { fail(rc, c); return; }
+            for (int k = lo; k < hi; k++) out[idx[(size_t)k]] = tmp[(size_t)(k - lo)];
         };
-        std::vector<int64_t> toffs;
-        for (size_t t = 0; t < mine.size() && !first_err.load(); t++) {
+        std::vector<const char *> bseq;
+        std::vector<int64_t> blen, toffs;
+        std::vector<int32_t> tst, tsp;
+        for (size_t t = 0; t < cuts.size() && !first_err.load(); t++) {
             if (t >= 2) collect(t - 2);
             phx_ctx *c = ln.ctx[t & 1];
-            const int lo = cuts[mine[t]].first, hi = cuts[mine[t]].second;
-            int rc = phx_upload(c, hi - lo, seq + lo, len + lo);
+            const int lo = cuts[t].first, hi = cuts[t].second;
+            bseq.clear(); blen.clear();
+            for (int k = lo; k < hi; k++) { bseq.push_back(seq[idx[(size_t)k]]); blen.push_back(len[idx[(size_t)k]]); }
+            int rc = phx_upload(c, hi - lo, bseq.data(), blen.data());
             if (!rc && trna_offsets) {
-                toffs.assign((size_t)(hi - lo) + 1, 0);
-                for (int i = lo; i <= hi; i++) toffs[(size_t)(i - lo)] = trna_offsets[i] - trna_offsets[lo];
-                rc = phx_set_trnas(c, toffs.data(), trna_start + trna_offsets[lo], trna_stop + trna_offsets[lo]);
+                toffs.assign(1, 0); tst.clear(); tsp.clear();
+                for (int k = lo; k < hi; k++) {
+                    const int i = idx[(size_t)k];
+                    for (int64_t q = trna_offsets[i]; q < trna_offsets[i + 1]; q++) { tst.push_back(trna_start[q]); tsp.push_back(trna_stop[q]); }
+                    toffs.push_back((int64_t)tst.size());
+                }
+                rc = phx_set_trnas(c, toffs.data(), tst.data(), tsp.data());
             }
             if (!rc) rc = phx_run_async(c);
             if (rc) { fail(rc, c); break; }
         }
-        if (!first_err.load()) for (size_t t = mine.size() >= 2 ? mine.size() - 2 : 0; t < mine.size(); t++) collect(t);
+        if (!first_err.load()) for (size_t t = cuts.size() >= 2 ? cuts.size() - 2 : 0; t < cuts.size(); t++) collect(t);
         else for (int k = 0; k < 2; k++) (void)phx_wait(ln.ctx[k]);
+    };
+    // (nothing may leave a lane's thread as an exception: a bad_alloc there would end the caller's process)
+    auto lane_work = [&](size_t j) {
+        try { lane_body(j); }
+        catch (...) {
+            int z = 0;
+            if (first_err.compare_exchange_strong(z, PHX_E_NOMEM)) { std::lock_guard<std::mutex> g(em); p->err = "out of memory in a lane's host thread"; }
+            for (int k = 0; k < 2; k++) (void)phx_wait(p->lanes[j].ctx[k]);
+        }
     };
     std::vector<std::thread> th;
     for (size_t j = 1; j < nl; j++) { try { th.emplace_back(lane_work, j); } catch (...) { first_err = PHX_E_NOMEM; break; } }
@@ -1882,9 +1932,10 @@ static int exact_fetch(phx_ctx *c, int32_t contig, ExactIn &in) {
 // The certificate, and for every contig it leaves open the reference's own arithmetic on the host (one worker thread per contig, at
 // most 32): phx_download* and phx_certified call this; its results replace the contig's genes.
 static int ensure_exact(phx_ctx *c) {
-    if (!c->certify || c->n == 0) return PHX_OK;
+    if (!c->certify || !c->exact || c->n == 0) return PHX_OK; // (exact off: the downloads hand out the device's lists, no certificate is computed for them)
     { const int rc = ensure_cert(c); if (rc) return rc; }
-    if (!c->exact || c->exact_done) return PHX_OK;
+    if (c->exact_done) return PHX_OK;
+    try { // (nothing may cross the C-ABI as an exception: the vectors below and the worker threads can run out of memory)
     std::vector<int> todo;
     for (int i = 0; i < c->n; i++) if (c->res[(size_t)i].status >= 0 && c->res[(size_t)i].cert == 0) todo.push_back(i);
     if (!todo.empty()) {
@@ -1893,7 +1944,14 @@ static int ensure_exact(phx_ctx *c) {
         for (size_t k = 0; k < todo.size(); k++) { const int rc = exact_fetch(c, todo[k], in[k]); if (rc) return rc; }
         const phx_params par = c->params;
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (;;) { const size_t k = next.fetch_add(1); if (k >= todo.size()) return; exact_solve(in[k], par, out[k]); } };
+        std::atomic<bool> oom{false};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= todo.size()) return;
+                try { exact_solve(in[k], par, out[k]); } catch (...) { out[k].failed = true; oom = true; }
+            }
+        };
         unsigned nt = std::thread::hardware_concurrency();
         if (nt < 1) nt = 1;
         if (nt > 32) nt = 32;
@@ -1902,12 +1960,14 @@ static int ensure_exact(phx_ctx *c) {
         for (unsigned t = 1; t < nt; t++) { try { th.emplace_back(work); } catch (...) { break; } }
         work();
         for (std::thread &t : th) t.join();
+        if (oom.load()) { c->err = "out of memory in the host re-solve"; return PHX_E_NOMEM; }
         for (size_t k = 0; k < todo.size(); k++) {
             if (out[k].failed) { c->exact_failed++; continue; }
             c->exact_genes[todo[k]] = std::move(out[k].genes);
             c->res[(size_t)todo[k]].cert = 2;
         }
     }
+    } catch (const std::bad_alloc &) { c->err = "out of memory in the host re-solve"; return PHX_E_NOMEM; }
     c->exact_done = true;
     return PHX_OK;
 }
@@ -2070,6 +2130,12 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
     return PHX_OK;
 }
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
+int64_t phx_plan_timeouts(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
+    return c->plan_timeouts;
+}
+
 int phx_batch_sizes(phx_ctx *c, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }

@@ -203,6 +203,8 @@ struct DTotals {
                          // bit 2: k_inorder's scratch (DBatch.tie) too small: tie_need bytes are wanted
     int64_t lds_need[4]; // per limb class: dynamic LDS k_sssp_lds needs (max over the contigs it may get)
     int64_t tie_need;    // bytes of scratch the contigs with equal-length alternative paths asked for (k_inorder)
+    int32_t plan_timeouts; // contigs whose k_sssp_wave gave up waiting for the planner it follows (DMeta.sssp_why 5) in this run: the host
+    int32_t pad_t;         //   then stops launching the solver beside its planner on this context (phx_plan_timeouts)
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold

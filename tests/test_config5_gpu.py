@@ -167,6 +167,30 @@ def test_one_process_spreads_batches_over_lanes(tmp_path):
     assert _cli("--gpus", "1", "--batch-bases", str(total // 5), fa) == single
 
 
+def test_pool_deals_a_skewed_input_longest_first():
+    """the contigs go to the lanes greedily, longest first, by the bases a lane already holds (phx_pool_annotate used to deal
+    consecutive batches round the lanes: fine for equal lengths, lopsided for one T4 among short contigs).  T4 + 200 short contigs —
+    some with tRNA hits, one with a bad letter, one too short — over two lanes on this box's one GPU: byte for byte what one context
+    gives, in input order, for several batch sizes."""
+    import phanotate_amd as pa
+
+    _, _, t4 = load_golden("NC_000866.1")
+    rng = np.random.RandomState(3)
+    seqs = [pa.synth_contig(5000 + i, int(rng.randint(400, 6000))) for i in range(60)] + [t4.encode()] + \
+           [pa.synth_contig(6000 + i, int(rng.randint(400, 6000))) for i in range(140)] + [b"acgtnnacgx" * 40, b"acg"]
+    hits = [[(100, 180)] if (i % 7 == 0 and len(s) > 400) else [] for i, s in enumerate(seqs)]
+    one = pa.Annotator()
+    want = one.annotate(seqs, trnas=hits)
+    one.close()
+    assert want[60][0] == 0 and len(want[60][1]) > 250 and want[-2][0] < 0 and want[-1][0] < 0
+    with pa.Pool(devices=[0, 0]) as pool:
+        for bb in (0, 40000, 1):
+            got = pool.annotate(seqs, trnas=hits, batch_bases=bb)
+            assert len(got) == len(want)
+            for k, ((ws, wg), (gs, gg)) in enumerate(zip(want, got)):
+                assert ws == gs and wg.tobytes() == gg.tobytes(), (bb, k)
+
+
 # ---- f-4: the other output formats, through the GPU path (README.md:45-54, 60-61, 67-68) ----
 def _cli(*args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "phanotate.py")] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
