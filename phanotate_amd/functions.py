@@ -133,11 +133,29 @@ class Graph(OrderedDict):
         return 0
 
 
+def edge_order(nd, ed):
+    """Indices of the tapped edges `ed` in Graph.iteredges order (graphs.py:121-126): by insertion rank of the source node, then
+    in the order get_graph adds a node's out-edges: its ORF edge(s) (functions.py:311-318), bridges (334-354), the tRNA edge
+    (509), the connect loop (360-438: right node outer, left node inner), source / target edges (440-452)."""
+    ref, typ, frm, pos = nd["refidx"].tolist(), nd["type"].tolist(), nd["frame"].tolist(), nd["pos"].tolist()  # (lists: structured scalars are slow)
+    keys = []
+    for k, (s, d) in enumerate(zip(ed["src"].tolist(), ed["dst"].tolist())):
+        ts, td, fs, fd = typ[s], typ[d], frm[s], frm[d]
+        if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
+            cls = (1.5 if abs(fs) == 4 else 0, ref[d], 0)
+        elif ts == 2 or td == 3:
+            cls = (3, ref[d], 0)
+        else:
+            l, r = (s, d) if pos[s] < pos[d] else (d, s)
+            cls = (1 if abs(pos[s] - pos[d]) >= 500 else 2, ref[r], ref[l])
+        keys.append((ref[s], cls, k))
+    keys.sort()
+    return [k for _, _, k in keys]
+
+
 def get_graph(my_orfs):
     """The graph libphx built for the contig of `my_orfs`, in the reference's insertion order; the weights are the device's
     fp64 values (phx_tap_edges), unchanged."""
-    from .dump import edge_order
-
     ann = my_orfs._ann
     nd = ann.nodes(0)
     ed = ann.edges(0)

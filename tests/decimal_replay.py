@@ -1,4 +1,8 @@
-"""-d/--dump (phanotate.py:58,61): one line per edge of the first contig's graph,
+"""TEST INFRASTRUCTURE (moved out of the product package in round 5; the product prints --dump with its own C replay, phx_dump_text /
+csrc/phx_exact.inc + phx_dec.c): the reference's Decimal arithmetic replayed with Python's own `decimal` module — the second,
+independent checker of the C replay, of k_refine's bounds and of the host re-solve.  Imported by tests/ and tools/ only.
+
+-d/--dump (phanotate.py:58,61): one line per edge of the first contig's graph,
     repr(source) TAB repr(target) TAB str(weight*1000)                      (edges.py:17-23, nodes.py:14-21)
 in Graph.iteredges order, with the reference's 28-digit Decimal weights, so that the text can be diffed against an
 upstream install line by line.
@@ -111,24 +115,7 @@ def orf_weights(seq, orf, gcc, gl, weights, start_names):
     return pstops, _Lazy(len(orf), weight_of)
 
 
-def edge_order(nd, ed):
-    """Indices of the tapped edges `ed` in Graph.iteredges order (graphs.py:121-126): by insertion rank of the source node, then
-    in the order get_graph adds a node's out-edges: its ORF edge(s) (functions.py:311-318), bridges (334-354), the tRNA edge
-    (509), the connect loop (360-438: right node outer, left node inner), source / target edges (440-452)."""
-    ref, typ, frm, pos = nd["refidx"].tolist(), nd["type"].tolist(), nd["frame"].tolist(), nd["pos"].tolist()  # (lists: structured scalars are slow)
-    keys = []
-    for k, (s, d) in enumerate(zip(ed["src"].tolist(), ed["dst"].tolist())):
-        ts, td, fs, fd = typ[s], typ[d], frm[s], frm[d]
-        if ts < 2 and td < 2 and fs == fd and ((fs > 0 and ts == 0 and td == 1) or (fs < 0 and ts == 1 and td == 0)):
-            cls = (1.5 if abs(fs) == 4 else 0, ref[d], 0)
-        elif ts == 2 or td == 3:
-            cls = (3, ref[d], 0)
-        else:
-            l, r = (s, d) if pos[s] < pos[d] else (d, s)
-            cls = (1 if abs(pos[s] - pos[d]) >= 500 else 2, ref[r], ref[l])
-        keys.append((ref[s], cls, k))
-    keys.sort()
-    return [k for _, _, k in keys]
+from phanotate_amd.functions import edge_order  # noqa: E402  (Graph.iteredges order: part of the product's functions mirror)
 
 
 def dump_lines(ann, i, seq, start_codons="atg:0.85,gtg:0.10,ttg:0.05"):

@@ -822,10 +822,10 @@ def test_dump_text_is_byte_exact(case, pa):
     """-d/--dump: the edge text of the reference (edges.py:17-23: repr(src), repr(dst), str(Decimal weight * 1000), in
     Graph.iteredges order), reproduced byte for byte by the library (phx_dump_text: csrc/phx_dec.c replays the reference's Decimal
     operations on the integers the GPU path delivers) and, as its cross-check, by the same replay with Python's own decimal
-    (phanotate_amd/dump.py).  The fixtures hold the md5 of the reference's own text."""
+    (tests/decimal_replay.py).  The fixtures hold the md5 of the reference's own text."""
     import hashlib
 
-    from phanotate_amd.dump import dump_lines
+    from decimal_replay import dump_lines
 
     g, name, seq = load_golden(case)
     if str(g["error"]):
@@ -846,7 +846,7 @@ def test_dump_text_is_byte_exact(case, pa):
 
 def test_paths_from_decimal_derived_integers(pa):
     """The reference hands fastpathz trunc(Decimal(w) * 1000) (28 digits), libphx solves on trunc(fp64(w) * 1000): the integers
-    differ in the low digits of large weights.  On fuzz contigs the Decimal weights (phanotate_amd/dump.py, the replay
+    differ in the low digits of large weights.  On fuzz contigs the Decimal weights (tests/decimal_replay.py, the replay
     behind the byte-exact --dump) solved with the golden generator's in-order Bellman-Ford in python ints give the node path
     libphx returns (tools/decimal_check.py runs the same over thousands of contigs)."""
     import sys
@@ -854,7 +854,7 @@ def test_paths_from_decimal_derived_integers(pa):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     from decimal_check import solve
     from fuzz_gpu import make
-    from phanotate_amd.dump import decimal_weights
+    from decimal_replay import decimal_weights
 
     rng = np.random.RandomState(77)
     seqs = []
@@ -1102,7 +1102,7 @@ def test_certificate_kernel_equals_its_python_statement(pa):
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import certify_probe
-    from phanotate_amd import dump
+    import decimal_replay as dump
 
     seqs = _fuzz_contigs(90, 77) + [pa.synth_contig(4000 + k, 30000).decode() for k in range(6)]
     n_fail = {False: 0, True: 0}
@@ -1152,7 +1152,7 @@ def test_refine_bounds_hold_on_every_fixture(pa):
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import certify_probe
-    from phanotate_amd import dump
+    import decimal_replay as dump
 
     n_edges = n_flag = 0
     for case in golden_cases():
@@ -1180,7 +1180,7 @@ def test_uncertified_contigs_are_solved_again_on_the_references_integers(pa, ora
     on exact integers) and its genes are replaced; phx_certified reports 2.  With the bounds inflated (cert_tight) that happens to
     most contigs of a batch: the result must equal the certified run's, byte for byte in the integers, the oracle's, and what the
     same replay gives in Python (dump.python_resolve: decimal.Decimal itself + python ints)."""
-    from phanotate_amd import dump
+    import decimal_replay as dump
 
     seqs = _fuzz_contigs(40, 91, 9000) + [pa.synth_contig(4100, 20000).decode()]
     plain = pa.Annotator()
@@ -1236,7 +1236,7 @@ def test_fp64_and_decimal_integers_disagree_on_the_neartie_pair(pa):
     genes must be the reference's for both.  For the one it got wrong the certificate fails (k_refine knows the reference's integers,
     the path is not optimal for them), the contig is solved again on the host in the reference's own arithmetic (phx_exact.inc), and the
     result differs from what the device alone reported."""
-    from phanotate_amd import dump
+    import decimal_replay as dump
 
     n_changed = 0
     raw_paths = []

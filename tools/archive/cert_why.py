@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import phanotate_amd as pa
 import certify_probe
-from phanotate_amd.dump import decimal_weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+from decimal_replay import decimal_weights
 from decimal_check import solve
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 seqs = [pa.synth_contig(i, 50000) for i in range(n)]

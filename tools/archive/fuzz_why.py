@@ -3,7 +3,9 @@ Decides with decimal.Decimal itself (dump.python_resolve: the reference's intege
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, phanotate_amd as pa
-from phanotate_amd import dump
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import decimal_replay as dump
 from oracle import oracle
 import fuzz_gpu
 seed = int(sys.argv[1]); n = int(sys.argv[2]) if len(sys.argv) > 2 else 300

@@ -9,7 +9,9 @@ print("certified", ann.certified().tolist(), "resolved", ann.resolved, "annotate
 t0 = time.perf_counter(); r2 = ann.annotate_flat(seqs); print("again %.3f s" % (time.perf_counter() - t0))
 # the full Decimal replay gives the same genes
 raw = ann._download_flat()
-from phanotate_amd import dump
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import decimal_replay as dump
 full = ann.resolve_uncertified(ann._seq_of, raw)  # flagged-only
 import phanotate_amd.api as api
 print("genes equal device:", all(a.tobytes() == b.tobytes() for a, b in zip(raw, r[:3])))

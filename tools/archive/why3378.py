@@ -2,7 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, phanotate_amd as pa, certify_probe
-from phanotate_amd import dump
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import decimal_replay as dump
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 3378
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 seqs = [pa.synth_contig(seed, L)]

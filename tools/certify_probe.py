@@ -23,7 +23,9 @@ import numpy as np
 import phanotate_amd as pa
 from decimal_check import solve
 from fuzz_gpu import make
-from phanotate_amd.dump import decimal_weights
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+from decimal_replay import decimal_weights
 
 
 def bounds_of(ed):

@@ -7,7 +7,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import phanotate_amd as pa
-from phanotate_amd import dump
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+import decimal_replay as dump
 from fuzz_gpu import make
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 nf = int(sys.argv[2]) if len(sys.argv) > 2 else 200

@@ -80,7 +80,9 @@ def main():
             if st >= 0 and status == 0 and g.n_node > 2: ties += 1 if g.tie else 0; fixed += 1 if g.tie == 2 else 0
             if not ok and cert[i] == 2:
                 # the fp64-level oracle and the reference's integers disagree: decimal.Decimal itself decides (dump.python_resolve)
-                from phanotate_amd import dump
+                import os as _os, sys as _sys
+                _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+                import decimal_replay as dump
                 py = dump.python_resolve(ann, i, part[i])
                 if [(int(x["left"]), int(x["right"]), int(x["strand"])) for x in genes] == [t[:3] for t in py]:
                     exact_wins += 1

@@ -36,7 +36,9 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.RandomState(seed)
     import phanotate_amd as pa
-    from phanotate_amd import dump
+    import os as _os, sys as _sys
+    _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+    import decimal_replay as dump
     bad = n = n_host = exact_wins = 0
     with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
         for b in range(nb):
