@@ -201,8 +201,12 @@ int phx_annotate(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t 
 void phx_free_results(phx_result *res, int32_t n);
 
 /* The same in three steps, so a caller can keep inputs resident in HBM and time phx_run alone. */
-int phx_upload(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *len); /* H2D of ASCII */
-/* Alternative to phx_upload: the concatenated ASCII is already in device memory (offsets on host, n+1 entries). */
+/* phx_upload: the letters are packed on the host — worker threads, into pinned memory — into the form the kernels read (residue-split
+ * bit planes, 3 bits per base: DESIGN.md §3) and copied piece by piece; it returns when the caller's strings are free again, the copies
+ * are ordered before the run on the context's stream. */
+int phx_upload(phx_ctx *ctx, int32_t n, const char *const *seq, const int64_t *len);
+/* Alternative to phx_upload: the concatenated ASCII is already in device memory (offsets on host, n+1 entries); a kernel at the head
+ * of every run packs it (the caller's buffer is only read, and must stay valid until the runs on it have ended). */
 int phx_attach(phx_ctx *ctx, int32_t n, const void *d_ascii, const int64_t *offsets);
 /* tRNA masking (functions.add_trnas, functions.py:457-509): the hits of an external tRNA finder for the contigs of the batch just
  * uploaded / attached, as the reference holds them in `trnas`: hits of contig i are (start[k], stop[k]) for k in
