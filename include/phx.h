@@ -49,7 +49,7 @@ extern "C" {
 #define PHX_S_TOOSHORT (-3)  /* L < 6 [UnboundLocalError/KeyError in GCframe.get, gc_frame_plot.py:53-69] */
 #define PHX_S_BADTRNA (-4)   /* phx_set_trnas: a hit of this contig has an end outside 1..L (no node can be placed there) */
 #define PHX_S_PARALLEL (-6)  /* a bridge edge duplicates a connect edge [ValueError, graphs.py:74] */
-#define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit) */
+#define PHX_S_OVERFLOW (-7)  /* path sums exceed the widest integer kernel (1088 bit: an ORF weight beyond ~1e300) AND the contig was not solved on the host: phx_download* solve such a contig in the reference's own unbounded arithmetic (phx_certified then reports 2) unless the context was created with PHX_CREATE_NO_EXACT / NO_CERTIFY */
 #define PHX_S_LONGORF (-8)   /* (no longer produced: until 0.3.0 an ORF of more than 65535 codons — 196 kb without an in-frame stop, a scaffold's N run —
                               * overflowed the 16-bit class counters; such ORFs are now counted in 32 bits, functions.py:286-298 has no limit) */
 #define PHX_S_NEGCYCLE (-9)  /* relaxation did not converge in V rounds */

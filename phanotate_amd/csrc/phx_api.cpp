@@ -158,6 +158,7 @@ struct phx_ctx {
     bool exact = true;       // phx_download* solve uncertified contigs again on the host (PHX_CREATE_NO_EXACT: they do not)
     bool exact_done = false; // ... and that has happened for the results the context holds
     std::map<int, std::vector<DGene>> exact_genes; // contig -> its genes from the host re-solve (phx_exact.inc)
+    std::vector<int> host_only;                    // contigs of the batch last run that no device kernel could solve (path sums beyond 1088 bits) and the host did: their status is PHX_S_OVERFLOW again when exactness is switched off
     int exact_failed = 0;    // contigs whose replay met an operation phx_dec.c does not restate (left as the device solved them)
     double cert_scale = 1.0;
     bool cert_wide = false; // test switch: every contig through k_certify_wide
@@ -707,11 +708,8 @@ int phx_upload(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len
         if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
         if ((rc = push_layout(c))) return rc;
         hipStream_t s0 = c->stream;
-        HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s0));
-        HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s0));
-        HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s0));
-        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)c->n, hipMemcpyDeviceToDevice, s0));
         fill_batch(c, &fb);
+        phxk_reset(&fb, c->b_meta0.p, (unsigned long long)(c->tot_nbits + 8), 0ull, s0); // (a new upload has no tRNA hits yet)
     }
     int n_sent = 0;
     struct Piece { int i0, i1; int64_t r0, r1; int items; };              // contigs [i0, i1) = records [r0, r1)
@@ -898,16 +896,12 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     hipStream_t s = c->stream;
     DBatch b;
     const bool head_done = c->eager_now; // phx_upload reset the accumulators and ran k_features behind its copies
+    fill_batch(c, &b);
     {
         StageTimer t(c, ST_MEMSET);
-        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_nbits.p, 0, (size_t)(c->tot_nbits + 8) * 8, s));
-        if (c->has_trna) HIPCHK(c, hipMemsetAsync(c->b_tbits.p, 0, (size_t)(c->tot_nbits / 3 * 4 + 8) * 8, s));
-        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_gtot.p, 0, 64, s));
-        if (!head_done) HIPCHK(c, hipMemsetAsync(c->b_tot.p, 0, sizeof(DTotals), s));
-    }
-    if (!head_done) {
-        StageTimer t(c, ST_COPY);
-        HIPCHK(c, hipMemcpyAsync(c->b_meta.p, c->b_meta0.p, sizeof(DMeta) * (size_t)n, hipMemcpyDeviceToDevice, s)); // accumulators back to zero
+        const unsigned long long tw = c->has_trna ? (unsigned long long)(c->tot_nbits / 3 * 4 + 8) : 0ull;
+        if (!head_done) phxk_reset(&b, c->b_meta0.p, (unsigned long long)(c->tot_nbits + 8), tw, s); // bitmaps, totals, per-contig accumulators: one launch
+        else if (c->has_trna) HIPCHK(c, hipMemsetAsync(c->b_tbits.p, 0, (size_t)tw * 8, s));
     }
     fill_batch(c, &b);
     if (!head_done) {
@@ -1119,7 +1113,7 @@ int push_layout(phx_ctx *c) {
 // later kernels then do nothing, and the caller runs again with `learn`.
 int launch_once(phx_ctx *c, bool learn) {
     int rc;
-    c->tapw_valid = false; c->cert_done = false; c->exact_done = false; c->exact_genes.clear(); c->exact_failed = 0;
+    c->tapw_valid = false; c->cert_done = false; c->exact_done = false; c->exact_genes.clear(); c->exact_failed = 0; c->host_only.clear();
     hipStream_t s = c->stream;
     c->eager_now = c->eager_done && !c->meta0_dirty && !c->tiles_dirty; // the first launch after such an upload only: a repeated or retried run does everything
     c->eager_done = false;
@@ -1551,6 +1545,8 @@ int phx_set_exact(phx_ctx *c, int on) {
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
     if (!on) { // the device's own lists again, for every contig
         for (auto &kv : c->exact_genes) if (c->res && kv.first < c->n) c->res[(size_t)kv.first].cert = 0;
+        for (int i : c->host_only) if (c->res && i < c->n) c->res[(size_t)i].status = PHX_S_OVERFLOW; // (the device has no genes for them)
+        c->host_only.clear();
         c->exact_genes.clear(); c->exact_done = false;
     }
     c->exact = on != 0;
@@ -1937,7 +1933,12 @@ static int ensure_exact(phx_ctx *c) {
     if (c->exact_done) return PHX_OK;
     try { // (nothing may cross the C-ABI as an exception: the vectors below and the worker threads can run out of memory)
     std::vector<int> todo;
-    for (int i = 0; i < c->n; i++) if (c->res[(size_t)i].status >= 0 && c->res[(size_t)i].cert == 0) todo.push_back(i);
+    { const int rm = fetch_meta(c); if (rm) return rm; }
+    // what the certificate left open, and the contigs no device kernel could take (DMeta.sssp_mode 4: path sums beyond 1088 bits)
+    for (int i = 0; i < c->n; i++) {
+        const DRes &r = c->res[(size_t)i];
+        if ((r.status >= 0 && r.cert == 0) || (r.status == PHX_S_OVERFLOW && c->meta[(size_t)i].status == 0 && c->meta[(size_t)i].sssp_mode == 4)) todo.push_back(i);
+    }
     if (!todo.empty()) {
         std::vector<ExactIn> in(todo.size());
         std::vector<ExactOut> out(todo.size());
@@ -1965,6 +1966,7 @@ static int ensure_exact(phx_ctx *c) {
             if (out[k].failed) { c->exact_failed++; continue; }
             c->exact_genes[todo[k]] = std::move(out[k].genes);
             c->res[(size_t)todo[k]].cert = 2;
+            if (c->res[(size_t)todo[k]].status == PHX_S_OVERFLOW) { c->res[(size_t)todo[k]].status = 0; c->host_only.push_back(todo[k]); }
         }
     }
     } catch (const std::bad_alloc &) { c->err = "out of memory in the host re-solve"; return PHX_E_NOMEM; }

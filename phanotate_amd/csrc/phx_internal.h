@@ -138,7 +138,8 @@ struct DMeta { // one per contig
     int32_t sssp_nl;   // 64-bit limbs this contig's path sums need (2, 4, 8 or 17)
     int32_t sssp_iters;
     int32_t sssp_why;  // why k_sssp_wave handed the contig back: 1 window limits, 2 spill list, 3 no convergence, 4 too many step-backs, 5 no progress of the planner it follows (0: it did not)
-    int32_t sssp_mode; // 0 = global-memory kernel, 1 = workgroup-per-contig LDS kernel, 2 = wavefront-per-contig kernel, 3 = that kernel's roomy configuration
+    int32_t sssp_mode; // 0 = global-memory kernel, 1 = workgroup-per-contig LDS kernel, 2 = wavefront-per-contig kernel, 3 = that kernel's roomy configuration,
+                       // 4 = no device kernel: the path sums exceed 1088 bits, the host solves the contig (phx_exact.inc)
     int32_t n_open;    // entries of olist that are open nodes (incl. the target); the close nodes follow
     int32_t dense;     // some node has more than ~62 close / open nodes within the next 500 bp: k_sssp_wave's windows cannot take it (k_edges<false>)
     double wsum;       // sum of |w*1000| over the ORF edges (fp64, order-dependent rounding: used as a bound only)
@@ -319,6 +320,7 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream);
 void phxk_refine(const DBatch *b, void *stream);  // before k_certify: the flagged edges once more in double-double (flags cleared / DBatch.eref)
 void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream); // after k_inorder: DMeta.cert
 void phxk_gene_pack(const DBatch *b, void *stream);
+void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_words, unsigned long long tbits_words, void *stream); // the head of a run: bitmaps, totals and per-contig records back to their start values
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }

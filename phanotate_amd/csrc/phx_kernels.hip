@@ -279,6 +279,12 @@ void phxk_gene_pack(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_gene_pack_a, dim3(g), dim3(LMB_T), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_gene_pack_b, dim3(g, 8), dim3(LMB_T), 0, (hipStream_t)stream, *b);
 }
+void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_words, unsigned long long tbits_words, void *stream) {
+    unsigned long long work = nbits_words / 2 + tbits_words / 2 + (unsigned long long)b->n_contig * (sizeof(DMeta) / 8);
+    unsigned g = (unsigned)((work + 255) / 256);
+    g = g < 1u ? 1u : (g > 4096u ? 4096u : g);
+    hipLaunchKernelGGL(k_reset, dim3(g), dim3(256), 0, (hipStream_t)stream, *b, (const DMeta *)meta0, nbits_words, tbits_words);
+}
 void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
 // one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs

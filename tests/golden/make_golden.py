@@ -327,6 +327,14 @@ def main():
     sense = [a + b + c for a in "acgt" for b in "acgt" for c in "acgt" if a + b + c not in ("taa", "tag", "tga")]
     body = "".join(sense[i] for i in wr.randint(0, len(sense), 9000))
     cases.append(("edge_wide", "edge_wide", synth(310, 3000) + "atg" + body + "taa" + synth(311, 3000), {}))
+    # path sums beyond the device's widest integers (missing #3): 21 000 sense codons without an in-frame start or stop
+    # behind one atg (63 kb, one ORF of the frame): weight ~ 1e350 — more than a double holds, more than 1088 bits; the reference's
+    # Decimal and the generator's python ints have no limit (CHANGELOG.md:11-13).  libphx solves such a contig on the host, in the
+    # reference's own arithmetic (phx_exact.inc), instead of refusing it with PHX_S_OVERFLOW.
+    wr = np.random.RandomState(12)
+    quiet = [c for c in sense if c not in ("atg", "gtg", "ttg")]
+    body2 = "".join(quiet[i] for i in wr.randint(0, len(quiet), 21000))
+    cases.append(("edge_huge", "edge_huge", synth(320, 3000) + "atg" + body2 + "taa" + synth(321, 3000), {}))
     # non-default flags (file_handling.py:51-53)
     cases.append(("param_minlen60", "param_minlen60", synth(200, 6000), dict(minlen=60)))
     cases.append(("param_codons", "param_codons", synth(201, 6000), dict(start_codons="atg:0.7,gtg:0.2,ttg:0.05,ctg:0.05", stop_codons="tag,taa")))

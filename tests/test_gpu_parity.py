@@ -135,6 +135,8 @@ def test_golden_case(case, pa, oracle):
         assert status < 0 and o["status"] < 0 and len(genes) == 0
         if str(g["error"]) == "ValueError":
             assert status == -6 and o["status"] == -6  # "parallel edges are forbidden", graphs.py:74 (PHX_S_PARALLEL)
+    elif case == "edge_huge":
+        return  # path sums beyond the device's integers: test_contig_beyond_the_device_integers_is_solved_on_the_host
     else:
         if case == "edge_wide":  # 431-bit path sums: the device's 512-bit class, the oracle's 1280-bit solver
             assert o["status"] == 0 and o["wide"] == 1 and status == 0 and ann.globals(0).n_limbs == 8
@@ -156,6 +158,56 @@ def test_golden_case(case, pa, oracle):
 
             assert format_tabular([name], np.array([status], np.int32), np.array([0, len(genes)], np.int64), genes).decode() == str(g["tabular"])  # CDS features only
     ann.close()
+
+
+def test_contig_beyond_the_device_integers_is_solved_on_the_host(pa, oracle):
+    """tests/golden/edge_huge (generated through the reference): one ORF of 21 000 sense codons, weight -1.13e331 — more than a double
+    holds, path sums of 1110 bits, beyond the device's widest integer class (1088).  The reference's Decimal and its solver's integers
+    have no limit (CHANGELOG.md:11-13); libphx used to refuse such a contig (PHX_S_OVERFLOW).  Now the device builds its graph, and
+    phx_download* solve it on the host in the reference's own arithmetic (phx_exact.inc: every flagged edge replayed in Decimal, the
+    in-place Bellman-Ford on integers as wide as the weights need): the reference's genes, certified == 2.  With exactness off the
+    status is PHX_S_OVERFLOW as before; the other contigs of the batch do not notice."""
+    g, name, seq = load_golden("edge_huge")
+    _, _, lam = load_golden("NC_001416.1")
+    gl_, _, _ = load_golden("NC_001416.1")
+    ann = pa.Annotator()
+    res = ann.annotate([lam, seq, pa.synth_contig(77, 9000)])
+    (s0, g0), (status, genes), (s2, g2) = res
+    assert s0 == 0 and s2 == 0 and np.array_equal(g0["left"], gl_["gene_left"])
+    assert status == 0
+    assert np.array_equal(genes["left"], g["gene_left"]) and np.array_equal(genes["right"], g["gene_right"])
+    assert np.array_equal(genes["strand"], g["gene_strand"].astype(np.int32))
+    fin = np.isfinite(g["gene_score"])
+    assert (~fin).sum() == 1 and np.array_equal(np.isfinite(genes["score"]), fin)  # '%E' % float(Decimal('-1.13E+331')) is -INF in the reference too
+    np.testing.assert_allclose(genes["score"][fin], g["gene_score"][fin], rtol=1e-6)
+    cert = ann.certified()
+    assert list(cert) == [1, 2, 1]
+    gl = ann.globals(1)
+    assert gl.n_limbs == 0 and gl.sssp_kernel == 4
+    # the structure the host solved on is the device's: ORF table and graph against the fixture
+    orf = ann.orfs(1)
+    for k, gk in (("start", "orf_start"), ("stop", "orf_stop"), ("frame", "orf_frame"), ("length", "orf_length"), ("rbs", "orf_rbs")):
+        assert np.array_equal(orf[k], g[gk]), k
+    nd = ann.nodes(1)
+    perm = np.argsort(nd["refidx"], kind="stable")
+    assert np.array_equal(nd["pos"][perm], g["node_pos"])
+    assert len(ann.edges(1)) == len(g["edge_src"])
+    # tabular text and --dump, byte for byte
+    from phanotate_amd.cli import format_tabular
+    import hashlib
+
+    assert format_tabular([name], np.array([status], np.int32), np.array([0, len(genes)], np.int64), genes).decode() == str(g["tabular"])
+    assert hashlib.md5(ann.dump_text(1)).hexdigest() == str(g["dump_md5"])
+    # exactness off: no device kernel has this contig's genes
+    st, offs, fl = ann.download_flat(exact=False)
+    assert list(st) == [0, -7, 0] and offs[2] - offs[1] == 0
+    st, offs, fl = ann.download_flat()
+    assert list(st) == [0, 0, 0] and offs[2] - offs[1] == len(g["gene_left"])
+    ann.close()
+    bare = pa.Annotator(flags=("no_exact",))
+    (sb, gb), = bare.annotate([seq])
+    assert sb == -7 and len(gb) == 0
+    bare.close()
 
 
 def test_readme_pins_on_gpu(pa):
