@@ -195,9 +195,11 @@ def main(argv=None):
             pipe = Pipeline(ann.params, device=device, depth=2, devices=([device] + [d for d in range(n_gpu) if d != device][: n_gpu - 1]) if n_gpu > 1 else None, first=ann)
             t1 = time.perf_counter()
             gen = ((fa.ptrs[idx[lo:hi]], fa.lens[idx[lo:hi]], fa, (lambda a=lo, b=hi: trnas_of(idx[a:b]))) for lo, hi in cuts)
-            parts = list(pipe.run(gen))
-            t2 = time.perf_counter()
-            pipe.close()
+            try:
+                parts = list(pipe.run(gen))
+                t2 = time.perf_counter()
+            finally:
+                pipe.close()
             t_parts["contexts_s"] = t1 - t0; t_parts["pipeline_s"] = t2 - t1; t_parts["gpus"] = n_gpu
         if len(parts) == 1:
             return parts[0]

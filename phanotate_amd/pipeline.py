@@ -111,8 +111,13 @@ class Pipeline:
             lane, busy = self.lanes[j], deque()
             try:
                 while True:
-                    item = inq[j].get()
-                    if item is None:
+                    try:  # (polls: on the consumer's error path the sentinel may not fit a full queue — the stop flag ends the worker then)
+                        item = inq[j].get(timeout=0.1)
+                    except queue.Empty:
+                        if stop.is_set():
+                            break
+                        continue
+                    if item is None or stop.is_set():
                         break
                     k, batch = item
                     if len(busy) == self.depth:
@@ -173,8 +178,8 @@ class Pipeline:
                     q.put_nowait(None)
                 except queue.Full:
                     pass
-            for t in threads:
-                t.join(timeout=30)
+            for t in threads:  # a lane's contexts may only be closed once its thread has really left them
+                t.join()
 
     def annotate_flat(self, batches):
         return list(self.run(batches))
