@@ -191,6 +191,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_POISON 256u    /* every device buffer the context allocates is filled with the byte 0xA5 first: the library must not depend on fresh memory being zero */
 #define PHX_CREATE_ONE_STREAM 512u /* no side streams: every kernel of a run on the context's one stream, in program order */
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
+#define PHX_CREATE_NO_FUSE 2048u /* batches of up to 4 contigs run their front end (ORF count ... edge fill) as the staged kernels of large batches, not as the one fused launch (k_front) */
 #define PHX_CREATE_NO_EXACT 1024u /* phx_download* hand out the device's gene lists as they are: no certificate is asked for and no contig is solved again on the host */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
@@ -315,6 +316,10 @@ const char *phx_stage_name(int k);
  * beside the solver's — other contexts or processes holding the SIMDs —, and after the first such run the context launches the solver
  * behind its planner.  0 on an undisturbed GPU. */
 int64_t phx_plan_timeouts(phx_ctx *ctx);
+/* Runs of this context whose front end was the single fused launch of small batches (k_front: steady-state runs of up to 4 contigs).
+ * Negative (-(runs) - 1): that kernel once waited ~4 ms at a grid barrier because its workgroups were not all resident (the GPU was
+ * shared), the run was repeated with the staged kernels, and the context has used those since. */
+int64_t phx_front_runs(phx_ctx *ctx);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
 int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
 

@@ -101,7 +101,7 @@ class Annotator:
     0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
     context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
-    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024}  # PHX_CREATE_* development / test switches
+    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024, "no_fuse": 2048}  # PHX_CREATE_* development / test switches
 
     def __init__(self, params=None, device=0, stream=None, flags=()):
         self.L = _lib.lib()
@@ -371,6 +371,10 @@ class Annotator:
         nl = (C.c_int32 * _lib.N_STAGES)()
         self._chk(self.L.phx_get_stage_ms(self.h, ms, nl, 1 if reset else 0), "phx_get_stage_ms")
         return {self.L.phx_stage_name(k).decode(): (float(ms[k]), int(nl[k])) for k in range(_lib.N_STAGES)}
+
+    def front_runs(self):
+        """Runs whose front end was the fused launch of small batches (phx_front_runs; negative: it was switched off after a stall)."""
+        return int(self.L.phx_front_runs(self.h))
 
     def plan_timeouts(self):
         """Contigs, over the life of the context, whose shortest-path wavefront gave up waiting for the planner it was launched beside

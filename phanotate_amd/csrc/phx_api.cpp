@@ -192,6 +192,9 @@ struct phx_ctx {
     int n_simd = 1024; // SIMDs of the device (4 per CU): places of k_sssp_wave
     bool force_global_sssp = false; // development switch: run every contig through the global-memory SSSP kernel
     bool no_wave = false, always_sync = false;
+    bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
+    bool front_off = false;        // k_front once waited too long at a grid barrier on this context (its workgroups were not all resident): staged kernels from then on
+    int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
     int64_t plan_timeouts = 0;     // contigs, over the life of the context, whose solver gave up waiting for the planner it follows (phx_plan_timeouts)
     bool plan_stream_off = false;  // ... after the first of them the solver is launched behind its planner again on this context
     float stage_ms[PHX_N_STAGES] = {0};
@@ -448,7 +451,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_meta, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
     if ((rc = ensure(c, c->b_tiles, 4 * (c->ftab.size() + 1)))) return rc;
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
-    if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32))) return rc;
+    if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32 + 512))) return rc; // (+ 48 time stamps of k_front in -DFRONT_PROFILE builds)
     if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
     if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes) + sizeof(DTotals)))) return rc; // (k_results appends the totals: one copy brings both to the host)
     if (c->res_cap < (size_t)c->n + 1) {
@@ -569,7 +572,7 @@ int phx_params_from_flags(const char *start_codons, const char *stop_codons, int
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT | PHX_CREATE_NO_FUSE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -590,6 +593,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->always_sync = (flags & PHX_CREATE_SIZE_EVERY_RUN) != 0;
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
     c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
+    c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
     c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
     c->poison = (flags & PHX_CREATE_POISON) != 0;
     c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
@@ -909,6 +913,19 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if (c->attached) phxk_pack_planes(&b, c->attached, s);
         phxk_features(&b, 0u, c->vtotal, s);
     }
+    // A small batch in steady state: everything from the ORF count to the edge fill in ONE launch (k_front, phx_front.inc) instead of
+    // two dozen launch-bound kernels.  (Not while the buffers are being sized — that needs the host between the stages — and not
+    // with the stage timers on.)
+    const uint32_t front_stages = (1u << ST_ORF_COUNT) | (1u << ST_ORF_EMIT) | (1u << ST_ORF_STATS) | (1u << ST_SCORE) | (1u << ST_NODES) | (1u << ST_EDGE_COUNT) | (1u << ST_EDGE_FILL);
+    const bool fuse = !learn && !(c->prof && (c->prof_mask & front_stages)) && !c->no_fuse && !c->front_off && phxk_front_blocks_y(&b) > 0;
+    DTotals *ht = c->h_tot;
+    if (fuse) {
+        b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0;
+        phxk_front(&b, s);
+        HIPCHK(c, hipGetLastError());
+        mask = c->last_mask;
+        for (int k = 0; k < 4; k++) lds[k] = c->last_lds[k];
+    } else {
     // word-prefix popcounts of the bitmaps (for k_orf_stats) on a side stream, beside the ORF scan
     HIPCHK(c, hipEventRecord(c->ev_fork_pre, s));
     HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_pre, 0));
@@ -916,7 +933,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipEventRecord(c->ev_join_pre, c->aux[0]));
     { StageTimer t(c, ST_ORF_COUNT); phxk_orf_count(&b, s); phxk_layout1(&b, s); }
     HIPCHK(c, hipGetLastError());
-    DTotals *ht = c->h_tot;
     if (learn) { // sync #1: totals of ORFs / groups / nodes -> buffers
         { StageTimer t(c, ST_COPY); HIPCHK(c, hipMemcpyAsync(ht, c->b_tot.p, sizeof(DTotals), hipMemcpyDeviceToHost, s)); }
         HIPCHK(c, hipStreamSynchronize(s));
@@ -973,6 +989,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if (mask & 4) mask |= 8; // k_wave_plan (still to run) may move 128-bit contigs to the wavefront kernel's roomy configuration: this run launches it in any case
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
     }
+    } // (!fuse)
     fill_batch(c, &b);
     // A contig's planner (one wavefront walking all its windows: 0.14 ms for Lambda, 0.25 ms for T4, 0.2-0.35 ms in a batch) outlasts the
     // edge fill it runs beside unless the batch is large (0.06 / 0.09 ms for a lone contig, 0.2 ms for 512 contigs), so the solver used to
@@ -1003,7 +1020,8 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         return PHX_OK;
     };
     if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
-    { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+    if (!fuse) { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+    else c->front_runs++;
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
@@ -1174,6 +1192,19 @@ int finish_once(phx_ctx *c) {
     memcpy(c->h_tot, (const void *)(c->res + (size_t)c->n), sizeof(DTotals)); // the totals came with the per-contig records
     const DTotals *ht = c->h_tot;
     c->tie_seen = std::max(c->tie_seen, ht->tie_need);
+#ifdef FRONT_PROFILE
+    if (getenv("PHX_DEBUG_FRONT")) {
+        int64_t st[40];
+        (void)hipMemcpy(st, (int64_t *)c->b_lpart.p + 16, sizeof st, hipMemcpyDeviceToHost);
+        fprintf(stderr, "k_front stamps (us, 100 MHz clock):");
+        for (int k = 1; k < 26; k++) fprintf(stderr, " %.1f", (double)(st[k] - st[k - 1]) * 0.01);
+        fprintf(stderr, "  total %.1f\n", (double)(st[25] - st[0]) * 0.01);
+    }
+#endif
+    if (ht->front_abort) { // k_front's workgroups were not all resident (other contexts / processes held the CUs): nothing of this run counts
+        c->front_off = true; c->graph_valid = false;
+        return kRetry;
+    }
     if (ht->plan_timeouts > 0) { c->plan_timeouts += ht->plan_timeouts; c->plan_stream_off = true; c->graph_valid = false; } // (the results stand: the workgroup kernel solved those contigs)
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = ((ht->class_mask & ~mask) & 0xffff) == 0; // (bits 16+: which classes have contigs for the side launch of the workgroup kernel: a matter of speed only)
@@ -2132,6 +2163,12 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
     return PHX_OK;
 }
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
+int64_t phx_front_runs(phx_ctx *c) {
+    if (!c) return PHX_E_ARG;
+    if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
+    return c->front_off ? -c->front_runs - 1 : c->front_runs;
+}
+
 int64_t phx_plan_timeouts(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }

@@ -205,7 +205,9 @@ struct DTotals {
     int64_t lds_need[4]; // per limb class: dynamic LDS k_sssp_lds needs (max over the contigs it may get)
     int64_t tie_need;    // bytes of scratch the contigs with equal-length alternative paths asked for (k_inorder)
     int32_t plan_timeouts; // contigs whose k_sssp_wave gave up waiting for the planner it follows (DMeta.sssp_why 5) in this run: the host
-    int32_t pad_t;         //   then stops launching the solver beside its planner on this context (phx_plan_timeouts)
+    int32_t front_abort;   //   then stops launching the solver beside its planner on this context (phx_plan_timeouts)
+    uint32_t gsync;        // k_front (small batches: the front end in one launch): arrivals at its grid barriers; front_abort: a workgroup
+    int32_t pad_t;         //   waited too long for the others (not all resident): the host runs the batch again with the staged kernels
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
@@ -321,6 +323,8 @@ void phxk_refine(const DBatch *b, void *stream);  // before k_certify: the flagg
 void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream); // after k_inorder: DMeta.cert
 void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_words, unsigned long long tbits_words, void *stream); // the head of a run: bitmaps, totals and per-contig records back to their start values
+int phxk_front_blocks_y(const DBatch *b); // workgroups per contig of k_front, 0: the batch is not one for it
+void phxk_front(const DBatch *b, void *stream); // small batches: ORF count ... edge fill in one launch (phx_front.inc)
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }

@@ -165,6 +165,7 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 #include "phx_graph.inc"
 #include "phx_sssp.inc"
 #include "phx_layout.inc"
+#include "phx_front.inc"
 #include "phx_sssp_wave.inc"
 #include "phx_inorder.inc"
 #include "phx_refine.inc"
@@ -284,6 +285,16 @@ void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_wor
     unsigned g = (unsigned)((work + 255) / 256);
     g = g < 1u ? 1u : (g > 4096u ? 4096u : g);
     hipLaunchKernelGGL(k_reset, dim3(g), dim3(256), 0, (hipStream_t)stream, *b, (const DMeta *)meta0, nbits_words, tbits_words);
+}
+int phxk_front_blocks_y(const DBatch *b) {
+    if (b->n_contig < 1 || b->n_contig > FRONT_MAX_CONTIGS || b->mean_len * b->n_contig > (128 << 10)) return 0; // (T4, 169 kb: its ORF count wants the 1024-thread workgroup of the staged kernel: 1.30 against 1.33 ms)
+    unsigned y = ysplit(b, 8);
+    while (y > 1 && (unsigned)b->n_contig * y > FRONT_MAX_BLOCKS) y--;
+    return (unsigned)b->n_contig * y <= FRONT_MAX_BLOCKS ? (int)y : 0;
+}
+void phxk_front(const DBatch *b, void *stream) {
+    const int y = phxk_front_blocks_y(b);
+    if (y > 0) hipLaunchKernelGGL(k_front, dim3(b->n_contig, y), dim3(NT), 0, (hipStream_t)stream, *b);
 }
 void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
