@@ -219,6 +219,10 @@ void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
+#ifndef NODES_STAGED
+    hipLaunchKernelGGL(k_nodes_fused, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+    return;
+#endif
     hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_build, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
