@@ -191,6 +191,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_POISON 256u    /* every device buffer the context allocates is filled with the byte 0xA5 first: the library must not depend on fresh memory being zero */
 #define PHX_CREATE_ONE_STREAM 512u /* no side streams: every kernel of a run on the context's one stream, in program order */
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
+#define PHX_CREATE_NO_DUO 4096u /* 128-bit contigs are solved by k_sssp_wave<2> (one wavefront per contig) instead of k_sssp_duo (a feeder and a solver wavefront per contig) */
 #define PHX_CREATE_NO_FUSE 2048u /* batches of up to 4 contigs run their front end (ORF count ... edge fill) as the staged kernels of large batches, not as the one fused launch (k_front) */
 #define PHX_CREATE_NO_EXACT 1024u /* phx_download* hand out the device's gene lists as they are: no certificate is asked for and no contig is solved again on the host */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);

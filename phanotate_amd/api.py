@@ -101,7 +101,7 @@ class Annotator:
     0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
     context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
-    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024, "no_fuse": 2048}  # PHX_CREATE_* development / test switches
+    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024, "no_fuse": 2048, "no_duo": 4096}  # PHX_CREATE_* development / test switches
 
     def __init__(self, params=None, device=0, stream=None, flags=()):
         self.L = _lib.lib()

@@ -193,6 +193,7 @@ struct phx_ctx {
     bool force_global_sssp = false; // development switch: run every contig through the global-memory SSSP kernel
     bool no_wave = false, always_sync = false;
     bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
+    bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     bool front_off = false;        // k_front once waited too long at a grid barrier on this context (its workgroups were not all resident): staged kernels from then on
     int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
     int64_t plan_timeouts = 0;     // contigs, over the life of the context, whose solver gave up waiting for the planner it follows (phx_plan_timeouts)
@@ -572,7 +573,7 @@ int phx_params_from_flags(const char *start_codons, const char *stop_codons, int
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT | PHX_CREATE_NO_FUSE)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT | PHX_CREATE_NO_FUSE | PHX_CREATE_NO_DUO)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -594,6 +595,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
     c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
     c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
+    { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
     c->poison = (flags & PHX_CREATE_POISON) != 0;
     c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
@@ -1006,6 +1008,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         else for (int k = 1; k <= 2; k++) if (((mask >> (4 * k + 2)) & 1) && !(mask & 0xffff & ~(15 << (4 * k)))) stream_k = k;
     }
     const bool stream_plan = stream_k >= 0;
+    b.duo = c->duo ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
     b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
     auto launch_plan = [&]() -> int { // the windows of the wavefront solver need the node records and in-edge counts only

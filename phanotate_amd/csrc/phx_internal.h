@@ -287,6 +287,7 @@ struct DBatch {
     int32_t *path;
     DGene *genes;
     uint32_t *gene_total;
+    int32_t duo;         // 128-bit contigs of the wavefront solver: k_sssp_duo (two wavefronts per contig) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO / PHX_NO_DUO: 0)
     int32_t plan_stream; // small batches (a lone contig's planner is longer than the edge fill it hides behind): 0, or the limb count (2, 4, 8) of the
                          // class whose k_sssp_wave is launched without waiting for its k_wave_plan and follows DMeta.plan_prog
     int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c

@@ -1419,7 +1419,7 @@ def test_create_flags_pick_the_solver_kernel_not_the_result(pa):
     want = base.annotate_flat(seqs)
     assert all(base.globals(i).sssp_kernel in (2, 3) for i in range(len(seqs)))
     base.close()
-    for flags, kern in ((("solver_global",), 0), (("solver_no_wave",), 1), (("no_graph", "size_every_run"), 2)):
+    for flags, kern in ((("solver_global",), 0), (("solver_no_wave",), 1), (("no_graph", "size_every_run"), 2), (("no_duo",), 2)):
         a = pa.Annotator(flags=flags)
         got = a.annotate_flat(seqs)
         for _ in range(3):

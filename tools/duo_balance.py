@@ -1,0 +1,25 @@
+"""Development (library built with EXTRA=-DDUO_PROFILE): where the two wavefronts of k_sssp_duo spend a contig's time on the benchmark
+batch.  Solver: waiting for a pack / taking it (header, ring entry, lane records, copy) / phases / results + step-back test.
+Feeder: part 1 (loads + conversion in registers) / waiting for the solver's acknowledgement / part 2 (side list, spill) / writing the pack."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import phanotate_amd as pa
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+seqs = [pa.synth_contig(i, 50000) for i in range(n)]
+ann = pa.Annotator(flags=("no_certify",))
+ann.annotate_flat(seqs)
+ann.run(); ann._download_flat()
+g = [ann.globals(i) for i in range(n)]
+t = np.array([x.rbs_background_count[6] for x in g]) / 100.0  # wall_clock64: 100 MHz -> us
+packs = np.array([x.rbs_background_count[7] for x in g])
+it = np.array([x.sssp_iters for x in g])
+print("solver wavefront per contig us: mean %.1f median %.1f p90 %.1f max %.1f min %.1f; packs %.1f, phases %.1f" % (t.mean(), np.median(t), np.percentile(t, 90), t.max(), t.min(), packs.mean(), it.mean()))
+o = np.argsort(-t)[:3]
+sp = np.array([[x.gc_max_count[j] for j in range(4)] for x in g]) / 100.0
+for j, nm in enumerate(("wait for the pack", "take the pack", "phases", "results + step-back test")):
+    print("  solver %-26s mean %6.1f us (%4.1f%%)  slowest contig %6.1f" % (nm, sp[:, j].mean(), 100 * sp[:, j].mean() / t.mean(), sp[o[0], j]))
+ft = np.array([[x.rbs_training_count[j] for j in range(6)] for x in g]).astype(float)
+for j, nm in enumerate(("part 1 (loads + convert)", "wait for the acknowledgement", "part 2 (side list, spill)", "write the pack")):
+    print("  feeder %-28s mean %6.1f us  slowest contig %6.1f" % (nm, ft[:, j].mean() / 100.0, ft[o[0], j] / 100.0))
+print("  feeder: packs with spill / side entries %.1f of %.1f" % (ft[:, 4].mean(), ft[:, 5].mean()))
