@@ -5,11 +5,17 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import phanotate_amd as pa
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-seqs = [pa.synth_contig(i, 50000) for i in range(n)]
+if len(sys.argv) > 1 and sys.argv[1] in ("lambda", "t4"):  # a lone genome (tests/golden)
+    import gzip
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", {"lambda": "NC_001416.1", "t4": "NC_000866.1"}[sys.argv[1]] + ".fasta.gz")
+    seqs = ["".join(l.strip() for l in gzip.open(f, "rt").read().split("\n")[1:])]
+    n = 1
+else:
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    seqs = [pa.synth_contig(i, 50000) for i in range(n)]
 ann = pa.Annotator(flags=("no_certify",))
 ann.annotate_flat(seqs)
-ann.run(); ann._download_flat()
+ann.run(); ann.run(); ann._download_flat()
 g = [ann.globals(i) for i in range(n)]
 t = np.array([x.rbs_background_count[6] for x in g]) / 100.0  # wall_clock64: 100 MHz -> us
 packs = np.array([x.rbs_background_count[7] for x in g])
@@ -23,3 +29,6 @@ ft = np.array([[x.rbs_training_count[j] for j in range(6)] for x in g]).astype(f
 for j, nm in enumerate(("part 1 (loads + convert)", "wait for the acknowledgement", "part 2 (side list, spill)", "write the pack")):
     print("  feeder %-28s mean %6.1f us  slowest contig %6.1f" % (nm, ft[:, j].mean() / 100.0, ft[o[0], j] / 100.0))
 print("  feeder: packs with spill / side entries %.1f of %.1f" % (ft[:, 4].mean(), ft[:, 5].mean()))
+ab = np.array([[x.rbs_background_count[j] for j in range(5)] for x in g]).astype(float)
+if ab[:, 2].sum() > 0:  # -DDUO_PROFILE_AB
+    print("  phases A: %.1f per contig, %.3f us each; B: %.1f, %.3f us each; exact phases %.1f" % (ab[:, 2].mean(), ab[:, 0].sum() / ab[:, 2].sum() / 100.0, ab[:, 3].mean(), ab[:, 1].sum() / ab[:, 3].sum() / 100.0, ab[:, 4].mean()))
