@@ -339,14 +339,8 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)
             dim3 t2(128);
-            const size_t lb = duo_lds_bytes<0>();
-            if (b->plan_stream == 2) {
-                (void)hipFuncSetAttribute((const void *)k_sssp_duo<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, lb, s, *b);
-            } else {
-                (void)hipFuncSetAttribute((const void *)k_sssp_duo<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
-                hipLaunchKernelGGL((k_sssp_duo<0, false>), g, t2, lb, s, *b);
-            }
+            if (b->plan_stream == 2) hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, 0, s, *b);
+            else hipLaunchKernelGGL((k_sssp_duo<0, false>), g, t2, 0, s, *b);
         } else if (nl == 2 && mode == 2) {
             const size_t lb = wv_lds_bytes<2, 0>();
             (void)hipFuncSetAttribute((const void *)k_sssp_wave<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
