@@ -192,6 +192,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_ONE_STREAM 512u /* no side streams: every kernel of a run on the context's one stream, in program order */
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
 #define PHX_CREATE_NO_DUO 4096u /* 128-bit contigs are solved by k_sssp_wave<2> (one wavefront per contig) instead of k_sssp_duo (a feeder and a solver wavefront per contig) */
+#define PHX_CREATE_NO_SEG 8192u /* small batches solve every contig by one sweep (one wavefront pair), not by up to 16 segments side by side that k_seg_merge joins and proves (phx_sssp_seg.inc) */
 #define PHX_CREATE_NO_FUSE 2048u /* batches of up to 4 contigs run their front end (ORF count ... edge fill) as the staged kernels of large batches, not as the one fused launch (k_front) */
 #define PHX_CREATE_NO_EXACT 1024u /* phx_download* hand out the device's gene lists as they are: no certificate is asked for and no contig is solved again on the host */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
@@ -321,6 +322,12 @@ int64_t phx_plan_timeouts(phx_ctx *ctx);
  * Negative (-(runs) - 1): that kernel once waited ~4 ms at a grid barrier because its workgroups were not all resident (the GPU was
  * shared), the run was repeated with the staged kernels, and the context has used those since. */
 int64_t phx_front_runs(phx_ctx *ctx);
+/* Runs of this context whose 128-bit contigs were solved in segments (batches of up to 64 contigs: a contig's shortest path by up to 16
+ * wavefront pairs side by side in frames of their own, joined by a constant each and PROVEN by one pass over the edges — k_seg_merge,
+ * phx_sssp_seg.inc; the delivered distances are the one-sweep solver's bit for bit).  Negative (-(runs) - 1): a run could not be joined or
+ * proven (segments whose shortest paths had not run together within the margin), it was repeated with one sweep per contig, and the
+ * context has solved that way since.  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
+int64_t phx_seg_runs(phx_ctx *ctx);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
 int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
 

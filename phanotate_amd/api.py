@@ -101,7 +101,7 @@ class Annotator:
     0 is HIP's null stream, which is what `torch.cuda.current_stream().cuda_stream` returns by default, so that the
     context's work is ordered after the caller's on that stream (phx_create_ex, PHX_CREATE_USE_STREAM)."""
 
-    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024, "no_fuse": 2048, "no_duo": 4096}  # PHX_CREATE_* development / test switches
+    FLAGS = {"no_graph": 2, "size_every_run": 4, "solver_global": 8, "solver_no_wave": 16, "no_certify": 32, "cert_tight": 64, "cert_wide": 128, "poison": 256, "one_stream": 512, "no_exact": 1024, "no_fuse": 2048, "no_duo": 4096, "no_seg": 8192}  # PHX_CREATE_* development / test switches
 
     def __init__(self, params=None, device=0, stream=None, flags=()):
         self.L = _lib.lib()
@@ -375,6 +375,10 @@ class Annotator:
     def front_runs(self):
         """Runs whose front end was the fused launch of small batches (phx_front_runs; negative: it was switched off after a stall)."""
         return int(self.L.phx_front_runs(self.h))
+
+    def seg_runs(self):
+        """Runs whose 128-bit contigs were solved in segments side by side (phx_seg_runs; negative: switched off after a run that could not be proven)."""
+        return int(self.L.phx_seg_runs(self.h))
 
     def plan_timeouts(self):
         """Contigs, over the life of the context, whose shortest-path wavefront gave up waiting for the planner it was launched beside

@@ -196,6 +196,14 @@ struct phx_ctx {
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     bool front_off = false;        // k_front once waited too long at a grid barrier on this context (its workgroups were not all resident): staged kernels from then on
     int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
+    // small batches: a contig's shortest path by up to 16 wavefront pairs side by side, joined and proven by k_seg_merge (phx_sssp_seg.inc)
+    bool seg_on = true;            // PHX_CREATE_NO_SEG, env PHX_NO_SEG=1: off
+    bool seg_off = false;          // a run on this context could not be joined or proven: one sweep per contig from then on
+    bool pend_seg = false;         // the run in flight uses segments
+    int seg_max_n = 64;            // batches of up to this many contigs (env PHX_SEG_MAX_N)
+    int seg_margin_bp = 6000;      // sequence a segment sweeps in front of what it commits (env PHX_SEG_MARGIN_BP; observed need: <= 3.2 kb)
+    int64_t seg_runs = 0, seg_aborts = 0; // phx_seg_runs
+    DevBuf b_swin, b_swrole, b_sdist, b_segw;
     int64_t plan_timeouts = 0;     // contigs, over the life of the context, whose solver gave up waiting for the planner it follows (phx_plan_timeouts)
     bool plan_stream_off = false;  // ... after the first of them the solver is launched behind its planner again on this context
     float stage_ms[PHX_N_STAGES] = {0};
@@ -371,6 +379,8 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->mreach = (uint32_t *)c->b_mreach.p;
     b->olist = (int32_t *)c->b_olist.p;
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
+    b->swin = (DWin *)c->b_swin.p; b->swrole = (uint2 *)c->b_swrole.p; b->sdist = (uint64_t *)c->b_sdist.p; b->segw = (int32_t *)c->b_segw.p;
+    b->sdist_nodes = b->caps.node; b->seg = 0; b->seg_margin_bp = c->seg_margin_bp;
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
@@ -573,7 +583,7 @@ int phx_params_from_flags(const char *start_codons, const char *stop_codons, int
 int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out) { return phx_create_ex(params, device, stream, stream ? PHX_CREATE_USE_STREAM : 0u, out); }
 
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out) {
-    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT | PHX_CREATE_NO_FUSE | PHX_CREATE_NO_DUO)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
+    if (!out || (flags & ~(PHX_CREATE_USE_STREAM | PHX_CREATE_NO_GRAPH | PHX_CREATE_SIZE_EVERY_RUN | PHX_CREATE_SOLVER_GLOBAL | PHX_CREATE_SOLVER_NO_WAVE | PHX_CREATE_NO_CERTIFY | PHX_CREATE_CERT_TIGHT | PHX_CREATE_CERT_WIDE | PHX_CREATE_POISON | PHX_CREATE_ONE_STREAM | PHX_CREATE_NO_EXACT | PHX_CREATE_NO_FUSE | PHX_CREATE_NO_DUO | PHX_CREATE_NO_SEG)) || (stream && !(flags & PHX_CREATE_USE_STREAM))) return PHX_E_ARG;
     *out = nullptr;
     int rc = check_params(params);
     if (rc) return rc;
@@ -596,6 +606,9 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
     c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
+    { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
+    { const char *e = getenv("PHX_SEG_MAX_N"); if (e && atoi(e) >= 0) c->seg_max_n = atoi(e); }
+    { const char *e = getenv("PHX_SEG_MARGIN_BP"); if (e && atoi(e) > 0) c->seg_margin_bp = atoi(e); }
     c->cert_wide = (flags & PHX_CREATE_CERT_WIDE) != 0;
     c->poison = (flags & PHX_CREATE_POISON) != 0;
     c->cert_scale = (flags & PHX_CREATE_CERT_TIGHT) ? 68719476736.0 : 1.0; // 2^36
@@ -640,7 +653,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_recs, &c->b_meta, &c->b_tiles, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord, &c->b_swin, &c->b_swrole, &c->b_sdist, &c->b_segw};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -881,6 +894,32 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
 
 static double host_contig_pstop(uint32_t gc, int L);
 
+// Segments (phx_sssp_seg.inc): wanted for this batch?  (The chip has a place per SIMD for a wavefront pair: 16 segments x 64 contigs.)
+static bool seg_wanted(const phx_ctx *c) {
+    return c->seg_on && !c->seg_off && c->duo && !c->force_global_sssp && !c->no_wave && c->n >= 1 && c->n <= c->seg_max_n && !sssp_ordered(c);
+}
+// their buffers, sized by what the context's node / window buffers hold (call after those have grown)
+static int ensure_seg(phx_ctx *c) {
+    if (!seg_wanted(c)) return PHX_OK;
+    DCaps k;
+    current_caps(c, &k);
+    if (k.node <= 0 || k.win <= 0 || k.node > (1ll << 22)) return PHX_OK; // (beyond 4 M nodes the slices would take GBs: such batches keep one sweep per contig)
+    const size_t KM = (size_t)phxk_seg_kmax();
+    int rc;
+    if ((rc = ensure(c, c->b_swin, KM * (size_t)(k.win + 8) * sizeof(DWin)))) return rc;
+    if ((rc = ensure(c, c->b_swrole, KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES))) return rc;
+    if ((rc = ensure(c, c->b_sdist, KM * (size_t)(k.node + 8) * 16))) return rc;
+    if ((rc = ensure(c, c->b_segw, KM * (size_t)(c->n + 1) * 8))) return rc;
+    return PHX_OK;
+}
+// ... and whether they hold this run
+static bool seg_ready(const phx_ctx *c, const DCaps &k) {
+    if (!seg_wanted(c) || k.node <= 0 || k.node > (1ll << 22)) return false;
+    const size_t KM = (size_t)phxk_seg_kmax();
+    return c->b_swin.p && c->b_swin.cap >= KM * (size_t)(k.win + 8) * sizeof(DWin) && c->b_swrole.p && c->b_swrole.cap >= KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES &&
+           c->b_sdist.p && c->b_sdist.cap >= KM * (size_t)(k.node + 8) * 16 && c->b_segw.p && c->b_segw.cap >= KM * (size_t)(c->n + 1) * 8;
+}
+
 namespace {
 
 const int kRetry = 1000; // run_once: a buffer was too small for this batch (or a solver class was not launched): run again, sizing as we go
@@ -964,6 +1003,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         const size_t NW = NV / 16 + 8 * (size_t)n + 16; // window records of k_sssp_wave, see k_layout1
         if ((rc = ensure(c, c->b_win, NW * sizeof(DWin)))) return rc;
         if ((rc = ensure(c, c->b_wrole, NW * sizeof(uint2) * WIN_ROLES))) return rc;
+        if ((rc = ensure_seg(c))) return rc;
     }
     fill_batch(c, &b);
     { StageTimer t(c, ST_ORF_EMIT); phxk_orf_emit(&b, s); }
@@ -987,6 +1027,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_ew, (size_t)(ht->edge + 1) * 8))) return rc;
         if ((rc = ensure(c, c->b_dist, ((size_t)ht->node + 8) * 8 * (size_t)c->n_limbs))) return rc;
         if (c->certify && (rc = ensure(c, c->b_csig, ((size_t)ht->node + 8) * 16 * (size_t)c->n_limbs))) return rc;
+        if ((rc = ensure_seg(c))) return rc; // (b_dist may have grown: the node capacity with it)
         mask = ht->class_mask;
         if (mask & 4) mask |= 8; // k_wave_plan (still to run) may move 128-bit contigs to the wavefront kernel's roomy configuration: this run launches it in any case
         for (int k = 0; k < 4; k++) lds[k] = ht->lds_need[k];
@@ -1007,6 +1048,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((mask >> 2) & 1) stream_k = 0;
         else for (int k = 1; k <= 2; k++) if (((mask >> (4 * k + 2)) & 1) && !(mask & 0xffff & ~(15 << (4 * k)))) stream_k = k;
     }
+    // Small batches: the 128-bit contigs of the wavefront solver in up to 16 segments each, all at once (phx_sssp_seg.inc); their planner
+    // wavefronts are short (a sixteenth of a contig), so the solver is launched behind them as in a large batch.
+    b.seg = (((mask >> 2) & 1) && seg_ready(c, b.caps)) ? 1 : 0;
+    c->pend_seg = b.seg != 0;
+    if (b.seg && stream_k == 0) stream_k = -1;
     const bool stream_plan = stream_k >= 0;
     b.duo = c->duo ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
@@ -1072,6 +1118,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         for (int a = 0; a < 2; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
         if (early || roomy_side) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
+        if (b.seg) phxk_seg_merge(&b, s); // join the segments, prove the distances, pick the parents (or give the run up: DTotals.seg_abort)
     }
     {
         StageTimer t(c, ST_INORDER);
@@ -1145,6 +1192,7 @@ int launch_once(phx_ctx *c, bool learn) {
     if ((rc = ensure(c, c->b_meta0, sizeof(DMeta) * (size_t)(c->n + 1)))) return rc;
     if ((rc = ensure(c, c->b_tie, (size_t)std::max<int64_t>(1 << 20, c->tie_seen + c->tie_seen / 4)))) return rc;
     if ((rc = push_layout(c))) return rc;
+    if (!learn && (rc = ensure_seg(c))) return rc;
     int mask = 0;
     int64_t lds[4] = {0, 0, 0, 0};
     DCaps caps_now;
@@ -1208,6 +1256,11 @@ int finish_once(phx_ctx *c) {
         c->front_off = true; c->graph_valid = false;
         return kRetry;
     }
+    if (ht->seg_abort) { // k_seg_merge could not join or prove some contig's segments (a margin too short for this genome, a window the tight planner cannot lay out): nothing of this run counts
+        c->seg_off = true; c->seg_aborts++; c->graph_valid = false;
+        return kRetry;
+    }
+    if (c->pend_seg) c->seg_runs++;
     if (ht->plan_timeouts > 0) { c->plan_timeouts += ht->plan_timeouts; c->plan_stream_off = true; c->graph_valid = false; } // (the results stand: the workgroup kernel solved those contigs)
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = ((ht->class_mask & ~mask) & 0xffff) == 0; // (bits 16+: which classes have contigs for the side launch of the workgroup kernel: a matter of speed only)
@@ -2166,6 +2219,10 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
     return PHX_OK;
 }
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
+int64_t phx_seg_runs(phx_ctx *c) {
+    if (!c) return 0;
+    return c->seg_off ? -c->seg_runs - 1 : c->seg_runs;
+}
 int64_t phx_front_runs(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }

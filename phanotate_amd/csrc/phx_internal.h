@@ -207,7 +207,8 @@ struct DTotals {
     int32_t plan_timeouts; // contigs whose k_sssp_wave gave up waiting for the planner it follows (DMeta.sssp_why 5) in this run: the host
     int32_t front_abort;   //   then stops launching the solver beside its planner on this context (phx_plan_timeouts)
     uint32_t gsync;        // k_front (small batches: the front end in one launch): arrivals at its grid barriers; front_abort: a workgroup
-    int32_t pad_t;         //   waited too long for the others (not all resident): the host runs the batch again with the staged kernels
+                           //   waited too long for the others (not all resident): the host runs the batch again with the staged kernels
+    int32_t seg_abort;     // k_seg_merge could not join or prove the segments of some contig: the host runs the batch again without segments
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
@@ -290,6 +291,14 @@ struct DBatch {
     int32_t duo;         // 128-bit contigs of the wavefront solver: k_sssp_duo (two wavefronts per contig) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO / PHX_NO_DUO: 0)
     int32_t plan_stream; // small batches (a lone contig's planner is longer than the edge fill it hides behind): 0, or the limb count (2, 4, 8) of the
                          // class whose k_sssp_wave is launched without waiting for its k_wave_plan and follows DMeta.plan_prog
+    // segments (phx_sssp_seg.inc): small batches — a contig's shortest path by up to SEG_KMAX wavefront pairs side by side, joined and proven by k_seg_merge
+    int32_t seg;          // 1: on for this run
+    int32_t seg_margin_bp; // sequence a segment sweeps in front of the nodes it commits
+    DWin *swin;           // window / lane records of the segments: SEG_KMAX x the capacity of `win` / `wrole`
+    uint2 *swrole;
+    uint64_t *sdist;      // distances in the segments' own frames: SEG_KMAX slices of sdist_nodes nodes, 2 words each
+    int64_t sdist_nodes;
+    int32_t *segw;        // per (contig, segment): windows laid out (-1: none), status of its solver (0: done)
     int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c
     DGene *genes_c;
 };
@@ -326,6 +335,8 @@ void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_words, unsigned long long tbits_words, void *stream); // the head of a run: bitmaps, totals and per-contig records back to their start values
 int phxk_front_blocks_y(const DBatch *b); // workgroups per contig of k_front, 0: the batch is not one for it
 void phxk_front(const DBatch *b, void *stream); // small batches: ORF count ... edge fill in one launch (phx_front.inc)
+void phxk_seg_merge(const DBatch *b, void *stream); // DBatch.seg: after the segment solvers (phxk_sssp mode 2, 128 bits): join + proof + parents
+int phxk_seg_kmax(void);
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }

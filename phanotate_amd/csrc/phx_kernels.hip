@@ -166,6 +166,7 @@ __device__ __forceinline__ int min_idx(int a, int b, int c) { return a > b ? (b 
 #include "phx_sssp.inc"
 #include "phx_layout.inc"
 #include "phx_front.inc"
+#include "phx_sssp_seg.inc"
 #include "phx_sssp_wave.inc"
 #include "phx_sssp_duo.inc"
 #include "phx_inorder.inc"
@@ -301,6 +302,8 @@ void phxk_front(const DBatch *b, void *stream) {
     const int y = phxk_front_blocks_y(b);
     if (y > 0) hipLaunchKernelGGL(k_front, dim3(b->n_contig, y), dim3(NT), 0, (hipStream_t)stream, *b);
 }
+void phxk_seg_merge(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_seg_merge, dim3(b->n_contig), dim3(SEGM_T), 0, (hipStream_t)stream, *b); }
+int phxk_seg_kmax(void) { return SEG_KMAX; }
 void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
 // one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs
@@ -323,7 +326,8 @@ int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4 || nl == 8; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
 // (may) hold 256-bit contigs for the wavefront kernel, whose lanes keep fewer in-edges
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
-    hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    if (b->seg) hipLaunchKernelGGL((k_wave_plan<2, 0, true>), dim3(b->n_contig * SEG_KMAX), dim3(64), 0, (hipStream_t)stream, *b); // one wavefront per segment
+    else hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL((k_wave_plan<2, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b); // the contigs the tight configuration could not take
     if (wide_too & 1) hipLaunchKernelGGL((k_wave_plan<4, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
     if (wide_too & 2) hipLaunchKernelGGL((k_wave_plan<8, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
@@ -339,7 +343,8 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)
             dim3 t2(128);
-            if (b->plan_stream == 2) hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, 0, s, *b);
+            if (b->seg) hipLaunchKernelGGL((k_sssp_duo<0, false, true>), dim3(b->n_contig * SEG_KMAX), t2, 0, s, *b); // a wavefront pair per segment (phx_sssp_seg.inc)
+            else if (b->plan_stream == 2) hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, 0, s, *b);
             else hipLaunchKernelGGL((k_sssp_duo<0, false>), g, t2, 0, s, *b);
         } else if (nl == 2 && mode == 2) {
             const size_t lb = wv_lds_bytes<2, 0>();
