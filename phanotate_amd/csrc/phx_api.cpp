@@ -198,9 +198,11 @@ struct phx_ctx {
     int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
     // small batches: a contig's shortest path by up to 16 wavefront pairs side by side, joined and proven by k_seg_merge (phx_sssp_seg.inc)
     bool seg_on = true;            // PHX_CREATE_NO_SEG, env PHX_NO_SEG=1: off
-    bool seg_off = false;          // a run on this context could not be joined or proven: one sweep per contig from then on
+    bool seg_off = false;          // a run on this batch could not be joined or proven: one sweep per contig until the next batch is uploaded
+    bool seg_never = false;        //   ... and for good once that has happened to more than a quarter of the runs
     bool pend_seg = false;         // the run in flight uses segments
-    int seg_max_n = 64;            // batches of up to this many contigs (env PHX_SEG_MAX_N)
+    int seg_max_n = 64;            // batches of up to this many contigs (env PHX_SEG_MAX_N): 16 segments per contig have a SIMD pair each; one contig that
+                                   // cannot be proven sends the whole batch through the one-sweep kernels again, so larger batches gain less than they risk
     int seg_margin_bp = 6000;      // sequence a segment sweeps in front of what it commits (env PHX_SEG_MARGIN_BP; observed need: <= 3.2 kb)
     int64_t seg_runs = 0, seg_aborts = 0; // phx_seg_runs
     DevBuf b_swin, b_swrole, b_sdist, b_segw;
@@ -407,6 +409,7 @@ int fetch_meta(phx_ctx *c) {
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     if (c->layout_pending) { HIPCHK(c, hipEventSynchronize(c->ev_layout)); c->layout_pending = false; } // push_layout's copies read the records rewritten below
     c->eager_done = false; c->trna_clean = true;
+    c->seg_off = false; // (segments get their chance on every new batch)
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     c->meta_stale = false;
     c->has_trna = false; c->h_tnode.clear();
@@ -894,30 +897,34 @@ int phx_attach(phx_ctx *c, int32_t n, const void *d_ascii, const int64_t *offset
 
 static double host_contig_pstop(uint32_t gc, int L);
 
-// Segments (phx_sssp_seg.inc): wanted for this batch?  (The chip has a place per SIMD for a wavefront pair: 16 segments x 64 contigs.)
-static bool seg_wanted(const phx_ctx *c) {
-    return c->seg_on && !c->seg_off && c->duo && !c->force_global_sssp && !c->no_wave && c->n >= 1 && c->n <= c->seg_max_n && !sssp_ordered(c);
+// Segments (phx_sssp_seg.inc): how many per contig at most in this batch (0: none).  The chip has a place per SIMD for a wavefront pair:
+// 32 segments x 32 contigs ... 2 x 512.
+static int seg_cap(const phx_ctx *c) {
+    if (!c->seg_on || c->seg_off || c->seg_never || !c->duo || c->force_global_sssp || c->no_wave || c->n < 1 || c->n > c->seg_max_n || sssp_ordered(c)) return 0;
+    const int k = std::min(phxk_seg_kmax(), c->n_simd / c->n);
+    return k >= 2 ? k : 0;
 }
+static bool seg_wanted(const phx_ctx *c) { return seg_cap(c) > 0; }
 // their buffers, sized by what the context's node / window buffers hold (call after those have grown)
 static int ensure_seg(phx_ctx *c) {
     if (!seg_wanted(c)) return PHX_OK;
     DCaps k;
     current_caps(c, &k);
     if (k.node <= 0 || k.win <= 0 || k.node > (1ll << 22)) return PHX_OK; // (beyond 4 M nodes the slices would take GBs: such batches keep one sweep per contig)
-    const size_t KM = (size_t)phxk_seg_kmax();
+    const size_t KM = (size_t)seg_cap(c);
     int rc;
     if ((rc = ensure(c, c->b_swin, KM * (size_t)(k.win + 8) * sizeof(DWin)))) return rc;
     if ((rc = ensure(c, c->b_swrole, KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES))) return rc;
     if ((rc = ensure(c, c->b_sdist, KM * (size_t)(k.node + 8) * 16))) return rc;
-    if ((rc = ensure(c, c->b_segw, KM * (size_t)(c->n + 1) * 8))) return rc;
+    if ((rc = ensure(c, c->b_segw, KM * (size_t)(c->n + 1) * 16))) return rc;
     return PHX_OK;
 }
 // ... and whether they hold this run
 static bool seg_ready(const phx_ctx *c, const DCaps &k) {
     if (!seg_wanted(c) || k.node <= 0 || k.node > (1ll << 22)) return false;
-    const size_t KM = (size_t)phxk_seg_kmax();
+    const size_t KM = (size_t)seg_cap(c);
     return c->b_swin.p && c->b_swin.cap >= KM * (size_t)(k.win + 8) * sizeof(DWin) && c->b_swrole.p && c->b_swrole.cap >= KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES &&
-           c->b_sdist.p && c->b_sdist.cap >= KM * (size_t)(k.node + 8) * 16 && c->b_segw.p && c->b_segw.cap >= KM * (size_t)(c->n + 1) * 8;
+           c->b_sdist.p && c->b_sdist.cap >= KM * (size_t)(k.node + 8) * 16 && c->b_segw.p && c->b_segw.cap >= KM * (size_t)(c->n + 1) * 16;
 }
 
 namespace {
@@ -1050,7 +1057,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     }
     // Small batches: the 128-bit contigs of the wavefront solver in up to 16 segments each, all at once (phx_sssp_seg.inc); their planner
     // wavefronts are short (a sixteenth of a contig), so the solver is launched behind them as in a large batch.
-    b.seg = (((mask >> 2) & 1) && seg_ready(c, b.caps)) ? 1 : 0;
+    b.seg = (((mask >> 2) & 1) && seg_ready(c, b.caps)) ? seg_cap(c) : 0;
     c->pend_seg = b.seg != 0;
     if (b.seg && stream_k == 0) stream_k = -1;
     const bool stream_plan = stream_k >= 0;
@@ -1258,6 +1265,8 @@ int finish_once(phx_ctx *c) {
     }
     if (ht->seg_abort) { // k_seg_merge could not join or prove some contig's segments (a margin too short for this genome, a window the tight planner cannot lay out): nothing of this run counts
         c->seg_off = true; c->seg_aborts++; c->graph_valid = false;
+        if (getenv("PHX_DEBUG_SEG")) fprintf(stderr, "segments: run given up (reasons %d: 1 nodes, 2 segment, 4 frames, 8 edges, 16 parents), %d contigs, cap %d\n", ht->seg_abort, c->n, seg_cap(c));
+        if (c->seg_aborts > 4 && 4 * c->seg_aborts > c->seg_runs + c->seg_aborts) c->seg_never = true;
         return kRetry;
     }
     if (c->pend_seg) c->seg_runs++;
@@ -2221,7 +2230,7 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
 int64_t phx_seg_runs(phx_ctx *c) {
     if (!c) return 0;
-    return c->seg_off ? -c->seg_runs - 1 : c->seg_runs;
+    return (c->seg_off || c->seg_never) ? -c->seg_runs - 1 : c->seg_runs;
 }
 int64_t phx_front_runs(phx_ctx *c) {
     if (!c) return PHX_E_ARG;

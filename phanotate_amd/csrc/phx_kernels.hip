@@ -302,7 +302,12 @@ void phxk_front(const DBatch *b, void *stream) {
     const int y = phxk_front_blocks_y(b);
     if (y > 0) hipLaunchKernelGGL(k_front, dim3(b->n_contig, y), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_seg_merge(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_seg_merge, dim3(b->n_contig), dim3(SEGM_T), 0, (hipStream_t)stream, *b); }
+void phxk_seg_merge(const DBatch *b, void *stream) {
+    int y = 2048 / (b->n_contig > 0 ? b->n_contig : 1);
+    y = y < 4 ? 4 : (y > 64 ? 64 : y);
+    hipLaunchKernelGGL(k_seg_join, dim3(b->n_contig, y), dim3(SEGJ_T), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_seg_close, dim3(b->n_contig), dim3(SEGM_T), 0, (hipStream_t)stream, *b);
+}
 int phxk_seg_kmax(void) { return SEG_KMAX; }
 void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
@@ -326,7 +331,7 @@ int phxk_sssp_wave_ok(int nl) { return nl == 2 || nl == 4 || nl == 8; }
 // windows and lane assignments of k_sssp_wave (needs the node records and in-edge offsets, not the edges); wide_too: the batch
 // (may) hold 256-bit contigs for the wavefront kernel, whose lanes keep fewer in-edges
 void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
-    if (b->seg) hipLaunchKernelGGL((k_wave_plan<2, 0, true>), dim3(b->n_contig * SEG_KMAX), dim3(64), 0, (hipStream_t)stream, *b); // one wavefront per segment
+    if (b->seg) hipLaunchKernelGGL((k_wave_plan<2, 0, true>), dim3(b->n_contig * b->seg), dim3(64), 0, (hipStream_t)stream, *b); // one wavefront per segment
     else hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL((k_wave_plan<2, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b); // the contigs the tight configuration could not take
     if (wide_too & 1) hipLaunchKernelGGL((k_wave_plan<4, 1>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
@@ -343,7 +348,7 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)
             dim3 t2(128);
-            if (b->seg) hipLaunchKernelGGL((k_sssp_duo<0, false, true>), dim3(b->n_contig * SEG_KMAX), t2, 0, s, *b); // a wavefront pair per segment (phx_sssp_seg.inc)
+            if (b->seg) hipLaunchKernelGGL((k_sssp_duo<0, false, true>), dim3(b->n_contig * b->seg), t2, 0, s, *b); // a wavefront pair per segment (phx_sssp_seg.inc)
             else if (b->plan_stream == 2) hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, 0, s, *b);
             else hipLaunchKernelGGL((k_sssp_duo<0, false>), g, t2, 0, s, *b);
         } else if (nl == 2 && mode == 2) {

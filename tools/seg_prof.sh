@@ -3,7 +3,7 @@
 # usage: tools/seg_prof.sh lambda|t4  (on the GPU box; writes gpurun_out/seg_prof_<name>.txt)
 name=${1:-lambda}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/segprof && rocprofv3 --kernel-trace --stats -d /tmp/segprof -o p -- python $GRAFT_REPO_ROOT/tools/seg_time.py $name > /dev/null 2>&1
+rm -rf /tmp/segprof && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/segprof -o p -- python $GRAFT_REPO_ROOT/tools/seg_time.py $name > /dev/null 2>&1
 python - "$name" <<'PY'
 import csv, glob, sys, os
 f = glob.glob("/tmp/segprof/**/p_kernel_stats.csv", recursive=True)
