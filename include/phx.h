@@ -322,12 +322,15 @@ int64_t phx_plan_timeouts(phx_ctx *ctx);
  * Negative (-(runs) - 1): that kernel once waited ~4 ms at a grid barrier because its workgroups were not all resident (the GPU was
  * shared), the run was repeated with the staged kernels, and the context has used those since. */
 int64_t phx_front_runs(phx_ctx *ctx);
-/* Runs of this context whose 128-bit contigs were solved in segments (batches of up to 512 contigs: a contig's shortest path by up to 32
- * wavefront pairs side by side in frames of their own, joined by a constant each and PROVEN by one pass over the edges — k_seg_merge,
- * phx_sssp_seg.inc; the delivered distances are the one-sweep solver's bit for bit).  Negative (-(runs) - 1): a run could not be joined or
- * proven (segments whose shortest paths had not run together within the margin), it was repeated with one sweep per contig, and the
- * context solves that way until the next batch is uploaded (for good once a quarter of its runs ended so).  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
+/* Runs of this context whose 128-bit contigs were solved in segments (batches of up to 64 contigs: a contig's shortest path by up to 32
+ * wavefront pairs side by side in frames of their own, joined by a constant each and PROVEN by one pass over the edges — k_seg_join /
+ * k_seg_close, phx_sssp_seg.inc).  A contig whose segments cannot be joined or proven (about 1 % of random contigs: every path downstream
+ * runs over an ORF edge from in front of a segment's margin) is solved by the one-sweep kernels in the same run: phx_seg_fallbacks counts
+ * them.  Either way the delivered distances, parents and genes are the one-sweep solver's bit for bit.  Negative (-(runs) - 1): a run met a
+ * contig neither way could take (windows only the roomy planner lays out), was repeated without segments, and the context solves that way
+ * until the next batch is uploaded.  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
 int64_t phx_seg_runs(phx_ctx *ctx);
+int64_t phx_seg_fallbacks(phx_ctx *ctx);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
 int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
 

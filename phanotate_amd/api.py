@@ -380,6 +380,10 @@ class Annotator:
         """Runs whose 128-bit contigs were solved in segments side by side (phx_seg_runs; negative: switched off after a run that could not be proven)."""
         return int(self.L.phx_seg_runs(self.h))
 
+    def seg_fallbacks(self):
+        """Contigs, over the life of the context, whose segments could not be joined or proven and that one sweep solved in the same run."""
+        return int(self.L.phx_seg_fallbacks(self.h))
+
     def plan_timeouts(self):
         """Contigs, over the life of the context, whose shortest-path wavefront gave up waiting for the planner it was launched beside
         (include/phx.h: phx_plan_timeouts): 0 unless other contexts / processes kept the planner's wavefronts off the device."""

@@ -201,10 +201,12 @@ struct phx_ctx {
     bool seg_off = false;          // a run on this batch could not be joined or proven: one sweep per contig until the next batch is uploaded
     bool seg_never = false;        //   ... and for good once that has happened to more than a quarter of the runs
     bool pend_seg = false;         // the run in flight uses segments
-    int seg_max_n = 64;            // batches of up to this many contigs (env PHX_SEG_MAX_N): 16 segments per contig have a SIMD pair each; one contig that
-                                   // cannot be proven sends the whole batch through the one-sweep kernels again, so larger batches gain less than they risk
+    int seg_presets = 0;           // contigs of this batch that go straight to the one sweep (their segments could not be proven in an earlier run)
+    bool seg_clean = false;        // a run of this batch has proven every contig's segments: later runs of it do not launch the one sweep behind them
+    int seg_max_n = 32;            // batches of up to this many contigs (env PHX_SEG_MAX_N): a contig that cannot be proven (~1 %) costs its one sweep on top,
+                                   // and a batch waits for it: beyond ~32 contigs that eats the gain
     int seg_margin_bp = 6000;      // sequence a segment sweeps in front of what it commits (env PHX_SEG_MARGIN_BP; observed need: <= 3.2 kb)
-    int64_t seg_runs = 0, seg_aborts = 0; // phx_seg_runs
+    int64_t seg_runs = 0, seg_aborts = 0, seg_fallbacks = 0; // phx_seg_runs; contigs, over the life of the context, that one sweep solved behind their segments
     DevBuf b_swin, b_swrole, b_sdist, b_segw;
     int64_t plan_timeouts = 0;     // contigs, over the life of the context, whose solver gave up waiting for the planner it follows (phx_plan_timeouts)
     bool plan_stream_off = false;  // ... after the first of them the solver is launched behind its planner again on this context
@@ -409,7 +411,7 @@ int fetch_meta(phx_ctx *c) {
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     if (c->layout_pending) { HIPCHK(c, hipEventSynchronize(c->ev_layout)); c->layout_pending = false; } // push_layout's copies read the records rewritten below
     c->eager_done = false; c->trna_clean = true;
-    c->seg_off = false; // (segments get their chance on every new batch)
+    c->seg_off = false; c->seg_clean = false; c->seg_presets = 0; // (segments get their chance on every new batch)
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     c->meta_stale = false;
     c->has_trna = false; c->h_tnode.clear();
@@ -1060,6 +1062,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     b.seg = (((mask >> 2) & 1) && seg_ready(c, b.caps)) ? seg_cap(c) : 0;
     c->pend_seg = b.seg != 0;
     if (b.seg && stream_k == 0) stream_k = -1;
+    b.seg_nofb = (b.seg && c->seg_clean && !learn) ? 1 : 0;
     const bool stream_plan = stream_k >= 0;
     b.duo = c->duo ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
@@ -1119,13 +1122,16 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
                 if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side) && !(stream_plan && k == stream_k && mode == 2)) {
                     if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
                     phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
+                    if (b.seg && k == 0 && mode == 2) { // the segments' solvers: join, prove, parents; then one sweep for the contigs that could not be proven
+                        phxk_seg_merge(&b, st);
+                        if (!b.seg_nofb) phxk_seg_fallback(&b, st);
+                    }
                 }
             nlaunch++;
         }
         for (int a = 0; a < 2; a++)
             if (used[a]) { HIPCHK(c, hipEventRecord(c->ev_join[a], c->aux[a])); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[a], 0)); }
         if (early || roomy_side) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[2], 0));
-        if (b.seg) phxk_seg_merge(&b, s); // join the segments, prove the distances, pick the parents (or give the run up: DTotals.seg_abort)
     }
     {
         StageTimer t(c, ST_INORDER);
@@ -1161,6 +1167,7 @@ int push_layout(phx_ctx *c) {
             m.off = k.off; m.L = k.L; m.nw = k.nw; m.rec_off = k.rec_off; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
             m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
             m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
+            m.seg_fail = k.seg_fail ? 64 : 0; // (segments: a contig they could not take in an earlier run of this batch goes straight to the one sweep)
             if ((k.status == PHX_S_PARALLEL || k.status == PHX_S_BADTRNA) && k.n_tedge < 0) { m.status = k.status; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74); a hit outside the contig
         }
         HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s)); // (pinned: set_batch_layout waits for ev_layout before it rewrites the records)
@@ -1264,12 +1271,17 @@ int finish_once(phx_ctx *c) {
         return kRetry;
     }
     if (ht->seg_abort) { // k_seg_merge could not join or prove some contig's segments (a margin too short for this genome, a window the tight planner cannot lay out): nothing of this run counts
-        c->seg_off = true; c->seg_aborts++; c->graph_valid = false;
-        if (getenv("PHX_DEBUG_SEG")) fprintf(stderr, "segments: run given up (reasons %d: 1 nodes, 2 segment, 4 frames, 8 edges, 16 parents), %d contigs, cap %d\n", ht->seg_abort, c->n, seg_cap(c));
+        c->seg_off = true; c->seg_clean = false; c->seg_aborts++; c->graph_valid = false;
+        if (getenv("PHX_DEBUG_SEG")) fprintf(stderr, "segments: run given up (reasons %d), %d contigs\n", ht->seg_abort, c->n);
         if (c->seg_aborts > 4 && 4 * c->seg_aborts > c->seg_runs + c->seg_aborts) c->seg_never = true;
         return kRetry;
     }
-    if (c->pend_seg) c->seg_runs++;
+    if (c->pend_seg && ht->seg_fallbacks) { // remember them for the next run of this batch (the records a run starts from)
+        for (int i = 0; i < c->n; i++)
+            if ((c->res[(size_t)i].seg_fail & ~64) && !c->meta[(size_t)i].seg_fail) { c->meta[(size_t)i].seg_fail = 64; c->meta0_dirty = true; c->seg_presets++; }
+    }
+    if (c->pend_seg && !ht->seg_fallbacks && !c->seg_presets && !c->seg_clean) { c->seg_clean = true; c->graph_valid = false; } // (the next runs of this batch are captured without the sweep behind the segments)
+    if (c->pend_seg) { c->seg_runs++; c->seg_fallbacks += ht->seg_fallbacks; if (ht->seg_fallbacks && getenv("PHX_DEBUG_SEG")) fprintf(stderr, "segments: %d of %d contigs solved by one sweep instead\n", ht->seg_fallbacks, c->n); }
     if (ht->plan_timeouts > 0) { c->plan_timeouts += ht->plan_timeouts; c->plan_stream_off = true; c->graph_valid = false; } // (the results stand: the workgroup kernel solved those contigs)
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
     bool covered = ((ht->class_mask & ~mask) & 0xffff) == 0; // (bits 16+: which classes have contigs for the side launch of the workgroup kernel: a matter of speed only)
@@ -2232,6 +2244,7 @@ int64_t phx_seg_runs(phx_ctx *c) {
     if (!c) return 0;
     return (c->seg_off || c->seg_never) ? -c->seg_runs - 1 : c->seg_runs;
 }
+int64_t phx_seg_fallbacks(phx_ctx *c) { return c ? c->seg_fallbacks : 0; }
 int64_t phx_front_runs(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }

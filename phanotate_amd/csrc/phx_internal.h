@@ -151,7 +151,7 @@ struct DMeta { // one per contig
     int32_t cert;      // k_certify: 1 the path is proven to be the one the reference's Decimal-derived integers give, 0 not proven (phx_certify.inc)
     int32_t plan_prog; // DBatch.plan_stream: windows whose records k_wave_plan<2,0> has published (| WV_PLAN_DONE when it has finished; -1: it
                        // gave the contig up) — k_sssp_wave<2,0> runs beside the planner and consumes the windows as they appear
-    int32_t pad_;
+    int32_t seg_fail;  // DBatch.seg: the segments of this contig could not be joined or proven (k_seg_join / k_seg_close): one sweep solves it in the same run (phxk_seg_fallback)
     int64_t rec_off;   // first record of this contig in DBatch.recs (2 nw + 1 records: the last one is all "outside")
 };
 
@@ -160,6 +160,8 @@ struct DRes {
     int32_t status, n_genes;
     int64_t gene_off;
     int32_t cert, tie; // DMeta.cert, DMeta.tie
+    int32_t seg_fail;  // DMeta.seg_fail: the host presets it (64) on the next run of the same batch, so that only the one sweep is spent on this contig
+    int32_t pad_r;
 };
 
 // k_refine -> k_certify, per edge that is still flagged "inexact": the reference's integer W* lies in [W + D - eps, W + D + eps], D = d1 + d2
@@ -208,7 +210,10 @@ struct DTotals {
     int32_t front_abort;   //   then stops launching the solver beside its planner on this context (phx_plan_timeouts)
     uint32_t gsync;        // k_front (small batches: the front end in one launch): arrivals at its grid barriers; front_abort: a workgroup
                            //   waited too long for the others (not all resident): the host runs the batch again with the staged kernels
-    int32_t seg_abort;     // k_seg_merge could not join or prove the segments of some contig: the host runs the batch again without segments
+    int32_t seg_abort;     // segments, and a contig neither they nor the one sweep behind them could take (more nodes than k_seg_close's table; windows the tight
+                           //   planner cannot lay out): the host runs the batch again without segments
+    int32_t seg_fallbacks; // contigs whose segments could not be joined or proven in this run (solved by one sweep behind them)
+    int32_t pad_t2;
 };
 struct DCaps {
     int64_t orf, grp, node, cb, edge; // elements the buffers of the context hold
@@ -294,6 +299,7 @@ struct DBatch {
     // segments (phx_sssp_seg.inc): small batches — a contig's shortest path by up to SEG_KMAX wavefront pairs side by side, joined and proven by k_seg_merge
     int32_t seg;          // 1: on for this run
     int32_t seg_margin_bp; // sequence a segment sweeps in front of the nodes it commits
+    int32_t seg_nofb;      // 1: the one sweep for flagged contigs is not launched in this run (an earlier run of the same batch flagged none): a flag now repeats the run
     DWin *swin;           // window / lane records of the segments: SEG_KMAX x the capacity of `win` / `wrole`
     uint2 *swrole;
     uint64_t *sdist;      // distances in the segments' own frames: SEG_KMAX slices of sdist_nodes nodes, 2 words each
@@ -337,6 +343,7 @@ int phxk_front_blocks_y(const DBatch *b); // workgroups per contig of k_front, 0
 void phxk_front(const DBatch *b, void *stream); // small batches: ORF count ... edge fill in one launch (phx_front.inc)
 void phxk_seg_merge(const DBatch *b, void *stream); // DBatch.seg: after the segment solvers (phxk_sssp mode 2, 128 bits): join + proof + parents
 int phxk_seg_kmax(void);
+void phxk_seg_fallback(const DBatch *b, void *stream); // ... and one sweep (k_wave_plan<2,0>, k_sssp_duo<0>) for the contigs k_seg_join / k_seg_close flagged (DMeta.seg_fail)
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them
 #ifdef __cplusplus
 }

@@ -309,6 +309,10 @@ void phxk_seg_merge(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_seg_close, dim3(b->n_contig), dim3(SEGM_T), 0, (hipStream_t)stream, *b);
 }
 int phxk_seg_kmax(void) { return SEG_KMAX; }
+void phxk_seg_fallback(const DBatch *b, void *stream) {
+    hipLaunchKernelGGL((k_wave_plan<2, 0>), dim3(b->n_contig), dim3(64), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL((k_sssp_duo<0, false>), dim3(b->n_contig), dim3(128), 0, (hipStream_t)stream, *b);
+}
 void phxk_results(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_results, dim3((unsigned)((b->n_contig + LMB_T - 1) / LMB_T)), dim3(LMB_T), 0, (hipStream_t)stream, *b); }
 size_t phxk_sssp_lds_bytes(int V, int nl) { return sssp_lds_bytes(V, nl); }
 // one workgroup for up to 1024 contigs; larger batches in two passes of a workgroup per 256 contigs

@@ -1,8 +1,8 @@
 """Segments (phx_sssp_seg.inc): in batches of up to 64 contigs a contig's shortest path (fastpathz, phanotate.py:56-64) is swept by up to 16
 wavefront pairs side by side, each in a frame of its own, and k_seg_merge joins the frames by a constant each and PROVES the result (no edge
 improves its head, every reached node has a tight parent, the parents lead to the source).  Bar: whatever is delivered is bit-equal to the
-one-sweep solver (PHX_CREATE_NO_SEG) — records, distances, parents' path — and to exact python-int distances; a run that cannot be proven
-is repeated without segments inside phx_run and delivers the same."""
+one-sweep solver (PHX_CREATE_NO_SEG) — records, distances, parents' path — and to exact python-int distances; a contig that cannot be
+proven is solved by one sweep in the same run and delivers the same."""
 import os
 
 import numpy as np
@@ -51,8 +51,9 @@ def _run(pa, seqs, flags, runs, sample, env=None):
     for i in sample:
         _exact(a, i)
     segs = a.seg_runs()
+    fb = a.seg_fallbacks()
     a.close()
-    return flat, dist, path, segs
+    return flat, dist, path, segs, fb
 
 
 def _same(x, y):
@@ -68,15 +69,15 @@ def test_lone_contig_in_segments_equals_one_sweep(pa, case):
     w = _run(pa, [seq], ("no_seg",), 3, (0,))
     _same(s, w)
     assert w[3] == 0
-    assert s[3] != 0  # segments were used (negative: tried, could not be proven, repeated with one sweep: allowed, the result stands)
+    assert s[3] == 3  # segments were used in every run
     if case in ("NC_001416.1", "NC_000866.1", "synth50k_0", "synth50k_5"):
-        assert s[3] == 3, s[3]  # these are proven at the default margin, every run
+        assert s[4] == 0, s[4]  # these are proven at the default margin
 
 
 def test_small_batches_in_segments(pa):
-    """8 and 40 contigs of 3-60 kb (16 segments x 64 contigs fill the chip), graph replay included."""
+    """8 and 30 contigs of 3-60 kb (segments are used in batches of up to 32 contigs), graph replay included."""
     rng = np.random.RandomState(11)
-    for n in (8, 40):
+    for n in (8, 30):
         seqs = [pa.synth_contig(900 + 13 * i + n, int(rng.randint(3000, 60000))) for i in range(n)]
         s = _run(pa, seqs, (), 3, (0, n // 2, n - 1))
         w = _run(pa, seqs, ("no_seg",), 2, (0, n // 2, n - 1))
@@ -84,15 +85,14 @@ def test_small_batches_in_segments(pa):
         assert s[3] != 0
 
 
-def test_a_margin_too_short_is_caught_and_the_run_repeated(pa):
-    """PHX_SEG_MARGIN_BP=1: 16 nodes (~400 bp) of margin — the frames have not run together; k_seg_merge must refuse (an offset that is not
-    one constant, an edge that improves its head, a node without a tight parent), phx_run repeats the batch with one sweep per contig, and
-    the context stays that way."""
+def test_a_margin_too_short_is_caught_and_one_sweep_solves_the_contig(pa):
+    """PHX_SEG_MARGIN_BP=300: the frames have not run together; k_seg_join must refuse (an edge that improves its head, a node without a
+    tight parent) and the one-sweep kernels behind it solve the flagged contigs in the same run."""
     seqs = [pa.synth_contig(40 + i, 50000) for i in range(6)]
-    s = _run(pa, seqs, (), 2, (0, 5), env={"PHX_SEG_MARGIN_BP": "1"})
+    s = _run(pa, seqs, (), 2, (0, 5), env={"PHX_SEG_MARGIN_BP": "300"})
     w = _run(pa, seqs, ("no_seg",), 1, (0, 5))
     _same(s, w)
-    assert s[3] < 0, s[3]
+    assert s[3] == 2 and s[4] >= 6, (s[3], s[4])  # both runs used segments; most contigs fell back, in each of them
 
 
 def test_margins_between_too_short_and_default(pa):
