@@ -504,7 +504,20 @@ def main():
                     t1 = (time.perf_counter() - t0) / 100
                     gl = a1.globals(0)
                     single[key] = {"contig": case, "bp": len(s1), "ms_per_contig": round(t1 * 1e3, 4), "Mbp_s": round(len(s1) / t1 / 1e6, 2), "genes": int(len(g1)),
-                                   "int_limbs": int(gl.n_limbs), "solver_kernel": int(gl.sssp_kernel), "status": int(st1)}
+                                   "int_limbs": int(gl.n_limbs), "solver_kernel": int(gl.sssp_kernel), "status": int(st1),
+                                   "runs_solved_in_segments": int(a1.seg_runs()), "contigs_solved_by_one_sweep_behind_them": int(a1.seg_fallbacks())}
+                    a1.close()
+                    # the same contig by ONE sweep (PHX_CREATE_NO_SEG): what the segments buy (phx_sssp_seg.inc: up to 32 wavefront pairs side by
+                    # side in frames of their own, joined and proven; the results are bit-equal, tests/test_seg_gpu.py)
+                    a1 = pa.Annotator(device=local_rank, flags=("no_seg",))
+                    a1.annotate([s1])
+                    for _ in range(60):
+                        a1.run()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(100):
+                        a1.run()
+                    single[key]["ms_per_contig_one_sweep"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
                     a1.close()
                 out["single_contig"] = single
             if args.workload == "synthetic" and n_total == 1000 and L_ == 50000:
