@@ -222,8 +222,12 @@ void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim
 // beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
 #ifndef NODES_STAGED
-    hipLaunchKernelGGL(k_nodes_fused, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
-    return;
+    // one workgroup per contig runs the four bodies in a row — unless the batch is a few LONG contigs (T4: one 256-thread workgroup then takes
+    // 111 us and k_node_attr waits for it; the staged kernels spread coverage and records over four workgroups per contig: 60 us)
+    if (!(b->n_contig <= 16 && b->mean_len >= 65536)) {
+        hipLaunchKernelGGL(k_nodes_fused, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
+        return;
+    }
 #endif
     hipLaunchKernelGGL(k_node_cov, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_node_rank, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
