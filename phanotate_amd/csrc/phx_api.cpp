@@ -216,6 +216,7 @@ struct phx_ctx {
     std::vector<hipEvent_t> ev_pool;
 };
 
+static int seg_cap(const phx_ctx *c); // segments per contig at most in the batch at hand (below)
 namespace {
 
 #define HIPCHK(ctx, call)                                                                                      \
@@ -385,6 +386,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
     b->swin = (DWin *)c->b_swin.p; b->swrole = (uint2 *)c->b_swrole.p; b->sdist = (uint64_t *)c->b_sdist.p; b->segw = (int32_t *)c->b_segw.p;
     b->sdist_nodes = b->caps.node; b->seg = 0; b->seg_margin_bp = c->seg_margin_bp;
+    { const size_t want = (size_t)seg_cap(c) * (size_t)c->n * 4, have = c->b_segw.p ? c->b_segw.cap / 4 : 0; b->segw_ints = (int32_t)std::min(want, have); if (!b->segw_ints) b->segw = nullptr; }
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
@@ -903,6 +905,7 @@ static double host_contig_pstop(uint32_t gc, int L);
 // 32 segments x 32 contigs ... 2 x 512.
 static int seg_cap(const phx_ctx *c) {
     if (!c->seg_on || c->seg_off || c->seg_never || !c->duo || c->force_global_sssp || c->no_wave || c->n < 1 || c->n > c->seg_max_n || sssp_ordered(c)) return 0;
+    if (c->max_len < (int64_t)c->seg_margin_bp + 4000) return 0; // (no contig long enough for two segments: the one sweep, which follows its planner, is 1-4 % faster then)
     const int k = std::min(phxk_seg_kmax(), c->n_simd / c->n);
     return k >= 2 ? k : 0;
 }
@@ -1063,6 +1066,9 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     c->pend_seg = b.seg != 0;
     if (b.seg && stream_k == 0) stream_k = -1;
     b.seg_nofb = (b.seg && c->seg_clean && !learn) ? 1 : 0;
+    // behind k_front (up to 4 contigs) no edge fill is left to hide the segments' planner wavefronts: their solvers are launched beside them and
+    // follow the window counts (DBatch.segw, cleared by k_reset at the head of this run); 128 pairs + 128 planner wavefronts are resident at once
+    b.seg_stream = (b.seg && fuse && !head_done && c->n <= 4 && !c->plan_stream_off && !c->one_stream && c->aux[3]) ? 1 : 0;
     const bool stream_plan = stream_k >= 0;
     b.duo = c->duo ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
@@ -1086,6 +1092,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         // wavefront kernel first, then the kernels it may hand contigs to
         StageTimer t(c, ST_SSSP);
         if (stream_plan) phxk_sssp(&b, 2 << stream_k, 2, (size_t)lds[stream_k], s); // beside the planner, see above
+        if (b.seg_stream) phxk_sssp(&b, 2, 2, (size_t)lds[0], s);                   // the segments' solvers, beside their planners
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join[3], 0)); // k_wave_plan: also decides which contigs the wavefront kernel takes
         const int nl_of[4] = {2, 4, 8, 17};
         int nlaunch = 0, nclass = 0;
@@ -1121,7 +1128,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
             for (int mode = 3; mode >= 0; mode--) // 3: the wavefront kernel's roomy configuration (few contigs, if any), 2: its tight one
                 if (((mask >> (4 * k + mode)) & 1) && !(mode == 3 && roomy_side) && !(stream_plan && k == stream_k && mode == 2)) {
                     if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
-                    phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
+                    if (!(b.seg_stream && k == 0 && mode == 2)) phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                     if (b.seg && k == 0 && mode == 2) { // the segments' solvers: join, prove, parents; then one sweep for the contigs that could not be proven
                         phxk_seg_merge(&b, st);
                         if (!b.seg_nofb) phxk_seg_fallback(&b, st);

@@ -299,6 +299,9 @@ struct DBatch {
     // segments (phx_sssp_seg.inc): small batches — a contig's shortest path by up to SEG_KMAX wavefront pairs side by side, joined and proven by k_seg_merge
     int32_t seg;          // 1: on for this run
     int32_t seg_margin_bp; // sequence a segment sweeps in front of the nodes it commits
+    int32_t seg_stream;    // 1: the segments' solvers are launched beside their planner wavefronts and follow DBatch.segw[.][0] as k_sssp_wave follows DMeta.plan_prog
+                           //    (batches of up to 4 contigs behind k_front: nothing else would hide the planner there)
+    int32_t segw_ints;     // ints of segw that k_reset clears at the head of a run
     int32_t seg_nofb;      // 1: the one sweep for flagged contigs is not launched in this run (an earlier run of the same batch flagged none): a flag now repeats the run
     DWin *swin;           // window / lane records of the segments: SEG_KMAX x the capacity of `win` / `wrole`
     uint2 *swrole;

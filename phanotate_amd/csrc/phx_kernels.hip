@@ -356,7 +356,8 @@ void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)
             dim3 t2(128);
-            if (b->seg) hipLaunchKernelGGL((k_sssp_duo<0, false, true>), dim3(b->n_contig * b->seg), t2, 0, s, *b); // a wavefront pair per segment (phx_sssp_seg.inc)
+            if (b->seg && b->seg_stream) hipLaunchKernelGGL((k_sssp_duo<0, true, true>), dim3(b->n_contig * b->seg), t2, 0, s, *b); // ... beside their planner wavefronts
+            else if (b->seg) hipLaunchKernelGGL((k_sssp_duo<0, false, true>), dim3(b->n_contig * b->seg), t2, 0, s, *b); // a wavefront pair per segment (phx_sssp_seg.inc)
             else if (b->plan_stream == 2) hipLaunchKernelGGL((k_sssp_duo<0, true>), g, t2, 0, s, *b);
             else hipLaunchKernelGGL((k_sssp_duo<0, false>), g, t2, 0, s, *b);
         } else if (nl == 2 && mode == 2) {

@@ -69,7 +69,7 @@ def test_lone_contig_in_segments_equals_one_sweep(pa, case):
     w = _run(pa, [seq], ("no_seg",), 3, (0,))
     _same(s, w)
     assert w[3] == 0
-    assert s[3] == 3  # segments were used in every run
+    assert s[3] == (3 if len(seq) >= 12000 else 0)  # segments were used in every run (a contig too short for two of them keeps the one sweep, which follows its planner)
     if case in ("NC_001416.1", "NC_000866.1", "synth50k_0", "synth50k_5"):
         assert s[4] == 0, s[4]  # these are proven at the default margin
 

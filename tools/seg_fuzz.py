@@ -41,7 +41,7 @@ for margin in ("6000",):
             giveups += 1
             if os.environ.get("PHX_DEBUG_SEG"):
                 print("  given up: synth_contig(%d, %d)" % (100000 * seed + i, L), flush=True)
-    print("lone contigs: %d runs, %d contigs solved by one sweep behind their segments, %d runs repeated without segments, %d mismatches" % (n_lone, fallbacks, giveups, bad), flush=True)
+    print("lone contigs: %d runs, %d contigs solved by one sweep behind their segments, %d runs without segments (contigs too short for two, or a run repeated), %d mismatches" % (n_lone, fallbacks, giveups, bad), flush=True)
     fallbacks = 0
     giveups = 0
     tot = 0
@@ -51,5 +51,5 @@ for margin in ("6000",):
         tot += n
         if one(seqs):
             giveups += 1
-    print("batches of 2-32: %d runs (%d contigs), %d contigs solved by one sweep behind their segments, %d runs repeated without segments, %d mismatches" % (n_batch, tot, fallbacks, giveups, bad), flush=True)
+    print("batches of 2-32: %d runs (%d contigs), %d contigs solved by one sweep behind their segments, %d runs without segments (contigs too short for two, or a run repeated), %d mismatches" % (n_batch, tot, fallbacks, giveups, bad), flush=True)
 sys.exit(1 if bad else 0)

@@ -15,6 +15,11 @@ def batch(name):
         return [load_golden("NC_001416.1")[2]]
     if name == "t4":
         return [load_golden("NC_000866.1")[2]]
+    if name == "phix":
+        return [load_golden("phiX174")[2]]
+    if name.startswith("short"):
+        n = int(name[5:])
+        return [pa.synth_contig(7 + i, 6000 + 500 * i) for i in range(n)]
     if name.startswith("synth"):
         n = int(name[5:])
         return [pa.synth_contig(i, 50000) for i in range(n)]
@@ -52,6 +57,6 @@ def timed(seqs, flags, env):
 
 for name in sys.argv[1:] or ["lambda", "t4", "synth8", "synth64"]:
     seqs = batch(name)
-    for label, flags, env in (("one sweep", ("no_seg",), {}), ("segments 6 kb", (), {}), ("segments 4 kb", (), {"PHX_SEG_MARGIN_BP": "4000"}), ("segments 9 kb", (), {"PHX_SEG_MARGIN_BP": "9000"})):
+    for label, flags, env in (("one sweep", ("no_seg",), {}), ("segments 6 kb", (), {}), ("seg, staged", ("no_fuse",), {}), ("segments 4 kb", (), {"PHX_SEG_MARGIN_BP": "4000"}), ("segments 9 kb", (), {"PHX_SEG_MARGIN_BP": "9000"})):
         ms, st, segs = timed(seqs, flags, env)
         print("%-8s %-14s step %.4f ms  sssp %.4f  wave_plan %.4f  edges_fill %.4f  inorder %.4f  seg_runs %d" % (name, label, ms, st.get("sssp", 0), st.get("wave_plan", 0), st.get("edges_fill", 0), st.get("inorder", 0), segs), flush=True)
