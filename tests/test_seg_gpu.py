@@ -85,6 +85,18 @@ def test_small_batches_in_segments(pa):
         assert s[3] != 0
 
 
+def test_staged_front_end_and_solvers_behind_their_planners(pa):
+    """Up to 4 contigs run their front end as one launch (k_front) and the segments' solvers beside their planner wavefronts; PHX_CREATE_NO_FUSE
+    keeps the staged kernels and launches the solvers behind the planners: the same records either way."""
+    seqs = [pa.synth_contig(70 + i, 30000 + 9000 * i) for i in range(3)]
+    f = _run(pa, seqs, (), 4, (0, 2))
+    s = _run(pa, seqs, ("no_fuse",), 4, (0, 2))
+    w = _run(pa, seqs, ("no_seg",), 2, (0, 2))
+    _same(f, w)
+    _same(s, w)
+    assert f[3] == 4 and s[3] == 4
+
+
 def test_a_margin_too_short_is_caught_and_one_sweep_solves_the_contig(pa):
     """PHX_SEG_MARGIN_BP=300: the frames have not run together; k_seg_join must refuse (an edge that improves its head, a node without a
     tight parent) and the one-sweep kernels behind it solve the flagged contigs in the same run."""
