@@ -322,13 +322,12 @@ int64_t phx_plan_timeouts(phx_ctx *ctx);
  * Negative (-(runs) - 1): that kernel once waited ~4 ms at a grid barrier because its workgroups were not all resident (the GPU was
  * shared), the run was repeated with the staged kernels, and the context has used those since. */
 int64_t phx_front_runs(phx_ctx *ctx);
-/* Runs of this context whose 128-bit contigs were solved in segments (batches of up to 64 contigs: a contig's shortest path by up to 32
- * wavefront pairs side by side in frames of their own, joined by a constant each and PROVEN by one pass over the edges — k_seg_join /
- * k_seg_close, phx_sssp_seg.inc).  A contig whose segments cannot be joined or proven (about 1 % of random contigs: every path downstream
- * runs over an ORF edge from in front of a segment's margin) is solved by the one-sweep kernels in the same run: phx_seg_fallbacks counts
- * them.  Either way the delivered distances, parents and genes are the one-sweep solver's bit for bit.  Negative (-(runs) - 1): a run met a
- * contig neither way could take (windows only the roomy planner lays out), was repeated without segments, and the context solves that way
- * until the next batch is uploaded.  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
+/* Runs of this context whose 128-bit contigs were solved in segments (batches of up to 32 contigs with a contig of 10 kb or more: a contig's
+ * shortest path by up to 32 wavefront pairs side by side in frames of their own, joined by a constant each and PROVEN by one pass over the
+ * edges — k_seg_join / k_seg_close, phx_sssp_seg.inc).  A contig whose segments cannot be joined or proven (about 2 % of random contigs:
+ * every path downstream runs over an ORF edge from in front of a segment's margin) is solved by the one-sweep kernels in the same run —
+ * phx_seg_fallbacks counts them — and later runs of that batch take the one-sweep kernels.  Either way the delivered distances, parents
+ * and genes are the one-sweep solver's bit for bit.  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
 int64_t phx_seg_runs(phx_ctx *ctx);
 int64_t phx_seg_fallbacks(phx_ctx *ctx);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */

@@ -198,10 +198,9 @@ struct phx_ctx {
     int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
     // small batches: a contig's shortest path by up to 16 wavefront pairs side by side, joined and proven by k_seg_merge (phx_sssp_seg.inc)
     bool seg_on = true;            // PHX_CREATE_NO_SEG, env PHX_NO_SEG=1: off
-    bool seg_off = false;          // a run on this batch could not be joined or proven: one sweep per contig until the next batch is uploaded
+    bool seg_off = false;          // a contig of this batch could not be joined or proven (it was solved by one sweep in the same run): one sweep per contig until the next batch is uploaded
     bool seg_never = false;        //   ... and for good once that has happened to more than a quarter of the runs
     bool pend_seg = false;         // the run in flight uses segments
-    int seg_presets = 0;           // contigs of this batch that go straight to the one sweep (their segments could not be proven in an earlier run)
     bool seg_clean = false;        // a run of this batch has proven every contig's segments: later runs of it do not launch the one sweep behind them
     int seg_max_n = 32;            // batches of up to this many contigs (env PHX_SEG_MAX_N): a contig that cannot be proven (~1 %) costs its one sweep on top,
                                    // and a batch waits for it: beyond ~32 contigs that eats the gain
@@ -413,7 +412,7 @@ int fetch_meta(phx_ctx *c) {
 int set_batch_layout(phx_ctx *c, int32_t n, const int64_t *len_or_null, const int64_t *offsets_or_null) {
     if (c->layout_pending) { HIPCHK(c, hipEventSynchronize(c->ev_layout)); c->layout_pending = false; } // push_layout's copies read the records rewritten below
     c->eager_done = false; c->trna_clean = true;
-    c->seg_off = false; c->seg_clean = false; c->seg_presets = 0; // (segments get their chance on every new batch)
+    c->seg_off = false; c->seg_clean = false; // (segments get their chance on every new batch)
     c->uploaded = false; c->ran = false; c->graph_valid = false; c->n = 0; // whatever fails below leaves the context without a batch
     c->meta_stale = false;
     c->has_trna = false; c->h_tnode.clear();
@@ -1174,7 +1173,6 @@ int push_layout(phx_ctx *c) {
             m.off = k.off; m.L = k.L; m.nw = k.nw; m.rec_off = k.rec_off; m.bits_off = k.bits_off; m.item_off = k.item_off; m.nbits_off = k.nbits_off;
             m.bridge_off = k.bridge_off; m.bridge_cap = k.bridge_cap;
             m.n_tnode = k.n_tnode; m.n_tedge = k.n_tedge; m.tn_off = k.tn_off; m.te_off = k.te_off;
-            m.seg_fail = k.seg_fail ? 64 : 0; // (segments: a contig they could not take in an earlier run of this batch goes straight to the one sweep)
             if ((k.status == PHX_S_PARALLEL || k.status == PHX_S_BADTRNA) && k.n_tedge < 0) { m.status = k.status; m.n_tedge = 0; } // two identical tRNA hits (ValueError graphs.py:74); a hit outside the contig
         }
         HIPCHK(c, hipMemcpyAsync(c->b_meta0.p, c->meta.data(), sizeof(DMeta) * (size_t)c->n, hipMemcpyHostToDevice, s)); // (pinned: set_batch_layout waits for ev_layout before it rewrites the records)
@@ -1283,11 +1281,10 @@ int finish_once(phx_ctx *c) {
         if (c->seg_aborts > 4 && 4 * c->seg_aborts > c->seg_runs + c->seg_aborts) c->seg_never = true;
         return kRetry;
     }
-    if (c->pend_seg && ht->seg_fallbacks) { // remember them for the next run of this batch (the records a run starts from)
-        for (int i = 0; i < c->n; i++)
-            if ((c->res[(size_t)i].seg_fail & ~64) && !c->meta[(size_t)i].seg_fail) { c->meta[(size_t)i].seg_fail = 64; c->meta0_dirty = true; c->seg_presets++; }
-    }
-    if (c->pend_seg && !ht->seg_fallbacks && !c->seg_presets && !c->seg_clean) { c->seg_clean = true; c->graph_valid = false; } // (the next runs of this batch are captured without the sweep behind the segments)
+    // A contig that fell back costs its planner and its one sweep BEHIND the segments of the others (0.13 + 0.27 ms for 50 kb: more than the
+    // segments gain on any batch): the results of this run stand, later runs of the same batch take the one-sweep kernels (which hide the planner)
+    if (c->pend_seg && ht->seg_fallbacks) { c->seg_off = true; c->graph_valid = false; }
+    if (c->pend_seg && !ht->seg_fallbacks && !c->seg_clean) { c->seg_clean = true; c->graph_valid = false; } // (the next runs of this batch are captured without the sweep behind the segments)
     if (c->pend_seg) { c->seg_runs++; c->seg_fallbacks += ht->seg_fallbacks; if (ht->seg_fallbacks && getenv("PHX_DEBUG_SEG")) fprintf(stderr, "segments: %d of %d contigs solved by one sweep instead\n", ht->seg_fallbacks, c->n); }
     if (ht->plan_timeouts > 0) { c->plan_timeouts += ht->plan_timeouts; c->plan_stream_off = true; c->graph_valid = false; } // (the results stand: the workgroup kernel solved those contigs)
     if (ht->overflow) { c->graph_valid = false; return kRetry; }
@@ -2249,7 +2246,7 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
 int64_t phx_seg_runs(phx_ctx *c) {
     if (!c) return 0;
-    return (c->seg_off || c->seg_never) ? -c->seg_runs - 1 : c->seg_runs;
+    return c->seg_runs;
 }
 int64_t phx_seg_fallbacks(phx_ctx *c) { return c ? c->seg_fallbacks : 0; }
 int64_t phx_front_runs(phx_ctx *c) {

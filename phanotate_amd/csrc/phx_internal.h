@@ -160,8 +160,6 @@ struct DRes {
     int32_t status, n_genes;
     int64_t gene_off;
     int32_t cert, tie; // DMeta.cert, DMeta.tie
-    int32_t seg_fail;  // DMeta.seg_fail: the host presets it (64) on the next run of the same batch, so that only the one sweep is spent on this contig
-    int32_t pad_r;
 };
 
 // k_refine -> k_certify, per edge that is still flagged "inexact": the reference's integer W* lies in [W + D - eps, W + D + eps], D = d1 + d2

@@ -99,12 +99,12 @@ def test_staged_front_end_and_solvers_behind_their_planners(pa):
 
 def test_a_margin_too_short_is_caught_and_one_sweep_solves_the_contig(pa):
     """PHX_SEG_MARGIN_BP=300: the frames have not run together; k_seg_join must refuse (an edge that improves its head, a node without a
-    tight parent) and the one-sweep kernels behind it solve the flagged contigs in the same run."""
+    tight parent) and the one-sweep kernels behind it solve the flagged contigs in the same run; later runs of the batch go without segments."""
     seqs = [pa.synth_contig(40 + i, 50000) for i in range(6)]
     s = _run(pa, seqs, (), 2, (0, 5), env={"PHX_SEG_MARGIN_BP": "300"})
     w = _run(pa, seqs, ("no_seg",), 1, (0, 5))
     _same(s, w)
-    assert s[3] == 2 and s[4] >= 6, (s[3], s[4])  # both runs used segments; most contigs fell back, in each of them
+    assert s[3] == 1 and s[4] >= 3, (s[3], s[4])  # the first run used segments and most contigs fell back; the second took the one-sweep kernels
 
 
 def test_margins_between_too_short_and_default(pa):
