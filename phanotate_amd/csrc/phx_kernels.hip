@@ -255,7 +255,7 @@ void phxk_inorder(const DBatch *b, int nl_mask, void *stream) {
     // the benchmark's kind of contig: 256 threads; batches of short contigs (a workgroup is one contig with a hundred nodes): one wavefront
     // and a quarter of the LDS for the path walk, so that four times as many contigs are in flight
     const bool small = b->mean_len < 8192;
-    const bool big = b->n_contig <= 64 && b->mean_len >= 65536; // a handful of long contigs: the chip is empty, a contig's one workgroup may as well be a large one
+    const bool big = (b->n_contig <= 64 && b->mean_len >= 65536) || (b->n_contig <= 8 && b->mean_len >= 16384); // a handful of long contigs (or a few of any length: Lambda): the chip is empty, a contig's one workgroup may as well be a large one — and its path walk goes in strides
     if (big && (nl_mask & 1)) { hipLaunchKernelGGL((k_inorder<2, IO_T_BIG>), g, dim3(IO_T_BIG), 0, s, *b); nl_mask &= ~1; }
     if (small) {
         if (nl_mask & 1) hipLaunchKernelGGL((k_inorder<2, 64>), g, dim3(64), 0, s, *b);
