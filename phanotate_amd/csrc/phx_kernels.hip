@@ -208,7 +208,9 @@ void phxk_pack_planes(const DBatch *b, const void *letters, void *stream) {
 #endif
 static unsigned ysplit(const DBatch *b, unsigned full) {
     const unsigned y = (unsigned)((b->mean_len + 8191) / 8192);
-    return y < 1u ? 1u : (y > full ? full : y);
+    // a few long contigs (T4 alone: 21 pieces of 8 kb) leave the chip empty: four times as many workgroups per contig while they all fit at once
+    const unsigned cap = (unsigned)b->n_contig * 4u * full <= 256u ? 4u * full : full;
+    return y < 1u ? 1u : (y > cap ? cap : y);
 }
 void phxk_orf_count(const DBatch *b, void *stream) {
     if (b->mean_len < 16384) hipLaunchKernelGGL((k_orf<false, 256>), dim3(b->n_contig), dim3(256), 0, (hipStream_t)stream, *b);
