@@ -330,6 +330,9 @@ int64_t phx_front_runs(phx_ctx *ctx);
  * and genes are the one-sweep solver's bit for bit.  PHX_CREATE_NO_SEG / env PHX_NO_SEG=1: never. */
 int64_t phx_seg_runs(phx_ctx *ctx);
 int64_t phx_seg_fallbacks(phx_ctx *ctx);
+/* development: the per-segment records of contig i in the run last made (8 ints each: windows | done flag, solver status, first node, end node, the solver's time in
+ * 10 ns ticks, phases, packs taken, step-backs); returns the number of records (0: that run did not use segments) */
+int phx_seg_stats(phx_ctx *ctx, int32_t i, int32_t *out, int32_t cap_records);
 /* sizes of the batch last run: positions, ORFs, nodes, edges (for the algorithmic-byte formula) */
 int phx_batch_sizes(phx_ctx *ctx, int64_t *L, int64_t *n_orf, int64_t *n_node, int64_t *n_edge);
 

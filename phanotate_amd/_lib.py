@@ -143,6 +143,7 @@ def lib():
         "phx_front_runs": (C.c_int64, [vp]),
         "phx_seg_runs": (C.c_int64, [vp]),
         "phx_seg_fallbacks": (C.c_int64, [vp]),
+        "phx_seg_stats": (C.c_int, [vp, C.c_int32, C.c_void_p, C.c_int32]),
         "phx_synth_contig": (C.c_int, [C.c_uint64, i64, C.c_char_p]),
         "phx_fasta_read": (C.c_int, [C.c_char_p, P(vp)]),
         "phx_fasta_count": (i32, [vp]),
@@ -164,5 +165,5 @@ def lib():
 EXPORTS = ["phx_version", "phx_device_count", "phx_strerror", "phx_last_error", "phx_default_params", "phx_params_from_flags", "phx_set_exact", "phx_pool_create", "phx_pool_destroy", "phx_pool_last_error", "phx_pool_annotate", "phx_dump_text", "phx_dec_eval", "phx_dd_eval", "phx_dd_shortest", "phx_create", "phx_create_ex", "phx_destroy",
            "phx_annotate", "phx_free_results", "phx_upload", "phx_attach", "phx_set_trnas", "phx_run", "phx_run_async", "phx_wait", "phx_download", "phx_download_flat", "phx_certified", "phx_tap_globals",
            "phx_tap_positions", "phx_tap_orfs", "phx_tap_nodes", "phx_tap_edges", "phx_tap_path", "phx_tap_dist", "phx_solve", "phx_set_profiling", "phx_set_profiling_stages",
-           "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_plan_timeouts", "phx_front_runs", "phx_seg_runs", "phx_seg_fallbacks", "phx_synth_contig", "phx_fasta_read", "phx_fasta_count",
+           "phx_get_stage_ms", "phx_stage_name", "phx_batch_sizes", "phx_plan_timeouts", "phx_front_runs", "phx_seg_runs", "phx_seg_fallbacks", "phx_seg_stats", "phx_synth_contig", "phx_fasta_read", "phx_fasta_count",
            "phx_fasta_record", "phx_fasta_arrays", "phx_fasta_free", "phx_format_tabular", "phx_free_text"]

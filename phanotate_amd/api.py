@@ -384,6 +384,14 @@ class Annotator:
         """Contigs, over the life of the context, whose segments could not be joined or proven and that one sweep solved in the same run."""
         return int(self.L.phx_seg_fallbacks(self.h))
 
+    def seg_stats(self, i):
+        """Per-segment records of contig i in the last run (phx_seg_stats): rows of [windows | done, status, first node, end node, ticks of 10 ns, phases, packs, step-backs]."""
+        import numpy as np
+
+        out = np.zeros((64, 8), np.int32)
+        n = self.L.phx_seg_stats(self.h, int(i), out.ctypes.data_as(C.c_void_p), 64)
+        return out[:n]
+
     def plan_timeouts(self):
         """Contigs, over the life of the context, whose shortest-path wavefront gave up waiting for the planner it was launched beside
         (include/phx.h: phx_plan_timeouts): 0 unless other contexts / processes kept the planner's wavefronts off the device."""

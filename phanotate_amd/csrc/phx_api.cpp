@@ -385,7 +385,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
     b->swin = (DWin *)c->b_swin.p; b->swrole = (uint2 *)c->b_swrole.p; b->sdist = (uint64_t *)c->b_sdist.p; b->segw = (int32_t *)c->b_segw.p;
     b->sdist_nodes = b->caps.node; b->seg = 0; b->seg_margin_bp = c->seg_margin_bp;
-    { const size_t want = (size_t)seg_cap(c) * (size_t)c->n * 4, have = c->b_segw.p ? c->b_segw.cap / 4 : 0; b->segw_ints = (int32_t)std::min(want, have); if (!b->segw_ints) b->segw = nullptr; }
+    { const size_t want = (size_t)seg_cap(c) * (size_t)c->n * 8, have = c->b_segw.p ? c->b_segw.cap / 4 : 0; b->segw_ints = (int32_t)std::min(want, have); if (!b->segw_ints) b->segw = nullptr; }
     b->dist = (uint64_t *)c->b_dist.p;
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
@@ -920,7 +920,7 @@ static int ensure_seg(phx_ctx *c) {
     if ((rc = ensure(c, c->b_swin, KM * (size_t)(k.win + 8) * sizeof(DWin)))) return rc;
     if ((rc = ensure(c, c->b_swrole, KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES))) return rc;
     if ((rc = ensure(c, c->b_sdist, KM * (size_t)(k.node + 8) * 16))) return rc;
-    if ((rc = ensure(c, c->b_segw, KM * (size_t)(c->n + 1) * 16))) return rc;
+    if ((rc = ensure(c, c->b_segw, KM * (size_t)(c->n + 1) * 32))) return rc;
     return PHX_OK;
 }
 // ... and whether they hold this run
@@ -928,7 +928,7 @@ static bool seg_ready(const phx_ctx *c, const DCaps &k) {
     if (!seg_wanted(c) || k.node <= 0 || k.node > (1ll << 22)) return false;
     const size_t KM = (size_t)seg_cap(c);
     return c->b_swin.p && c->b_swin.cap >= KM * (size_t)(k.win + 8) * sizeof(DWin) && c->b_swrole.p && c->b_swrole.cap >= KM * (size_t)(k.win + 8) * sizeof(uint2) * WIN_ROLES &&
-           c->b_sdist.p && c->b_sdist.cap >= KM * (size_t)(k.node + 8) * 16 && c->b_segw.p && c->b_segw.cap >= KM * (size_t)(c->n + 1) * 16;
+           c->b_sdist.p && c->b_sdist.cap >= KM * (size_t)(k.node + 8) * 16 && c->b_segw.p && c->b_segw.cap >= KM * (size_t)(c->n + 1) * 32;
 }
 
 namespace {
@@ -2249,6 +2249,16 @@ int64_t phx_seg_runs(phx_ctx *c) {
     return c->seg_runs;
 }
 int64_t phx_seg_fallbacks(phx_ctx *c) { return c ? c->seg_fallbacks : 0; }
+// development: the records of the segments of contig `i` in the run last made — 8 ints each: windows | done flag, solver status, first node, end node, solver time
+// (10 ns ticks), phases, packs, step-backs; returns the number of records written (0: the run did not use segments)
+int phx_seg_stats(phx_ctx *c, int32_t i, int32_t *out, int32_t cap_records) {
+    if (!c || !out || i < 0 || i >= c->n || !c->ran || !c->pend_seg || !c->b_segw.p) return 0;
+    const int K = seg_cap(c) > 0 ? seg_cap(c) : 0;
+    const int n = std::min(K, (int)cap_records);
+    if (n <= 0) return 0;
+    if (hipMemcpy(out, (const int32_t *)c->b_segw.p + (size_t)i * (size_t)K * 8, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
 int64_t phx_front_runs(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (c->in_flight) { const int rs = phx_wait(c); if (rs) return rs; }
