@@ -193,7 +193,7 @@ int phx_create(const phx_params *params, int device, void *stream, phx_ctx **out
 #define PHX_CREATE_CERT_WIDE 128u /* every contig through the certificate's general kernel (otherwise only contigs of more than 12288 nodes) */
 #define PHX_CREATE_NO_DUO 4096u /* 128-bit contigs are solved by k_sssp_wave<2> (one wavefront per contig) instead of k_sssp_duo (a feeder and a solver wavefront per contig) */
 #define PHX_CREATE_NO_SEG 8192u /* small batches solve every contig by one sweep (one wavefront pair), not by up to 16 segments side by side that k_seg_merge joins and proves (phx_sssp_seg.inc) */
-#define PHX_CREATE_NO_FUSE 2048u /* batches of up to 4 contigs run their front end (ORF count ... edge fill) as the staged kernels of large batches, not as the one fused launch (k_front) */
+#define PHX_CREATE_NO_FUSE 2048u /* batches of up to 4 contigs and 40 kb in all run their front end (ORF count ... edge fill) as the staged kernels of large batches, not as the one fused launch (k_front) */
 #define PHX_CREATE_NO_EXACT 1024u /* phx_download* hand out the device's gene lists as they are: no certificate is asked for and no contig is solved again on the host */
 int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t flags, phx_ctx **out);
 void phx_destroy(phx_ctx *ctx);
@@ -318,7 +318,7 @@ const char *phx_stage_name(int k);
  * beside the solver's — other contexts or processes holding the SIMDs —, and after the first such run the context launches the solver
  * behind its planner.  0 on an undisturbed GPU. */
 int64_t phx_plan_timeouts(phx_ctx *ctx);
-/* Runs of this context whose front end was the single fused launch of small batches (k_front: steady-state runs of up to 4 contigs).
+/* Runs of this context whose front end was the single fused launch of small batches (k_front: steady-state runs of up to 4 contigs and 40 kb in all).
  * Negative (-(runs) - 1): that kernel once waited ~4 ms at a grid barrier because its workgroups were not all resident (the GPU was
  * shared), the run was repeated with the staged kernels, and the context has used those since. */
 int64_t phx_front_runs(phx_ctx *ctx);

@@ -299,7 +299,7 @@ void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_wor
     hipLaunchKernelGGL(k_reset, dim3(g), dim3(256), 0, (hipStream_t)stream, *b, (const DMeta *)meta0, nbits_words, tbits_words);
 }
 int phxk_front_blocks_y(const DBatch *b) {
-    if (b->n_contig < 1 || b->n_contig > FRONT_MAX_CONTIGS || b->mean_len * b->n_contig > (128 << 10)) return 0; // (T4, 169 kb: its ORF count wants the 1024-thread workgroup of the staged kernel: 1.30 against 1.33 ms)
+    if (b->n_contig < 1 || b->n_contig > FRONT_MAX_CONTIGS || b->mean_len * b->n_contig > (40 << 10)) return 0; // (since the staged kernels of a few long contigs run with four times as many workgroups per contig — ysplit — they win from ~32 kb on: 8 / 16 / 24 kb fused 0.273 / 0.304 / 0.307 ms against 0.291 / 0.314 / 0.314 staged, 32 kb 0.313 / 0.312, Lambda 0.369 / 0.360, 2 x 50 kb 0.395 / 0.376)
     unsigned y = ysplit(b, 8);
     while (y > 1 && (unsigned)b->n_contig * y > FRONT_MAX_BLOCKS) y--;
     return (unsigned)b->n_contig * y <= FRONT_MAX_BLOCKS ? (int)y : 0;

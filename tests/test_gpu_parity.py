@@ -166,7 +166,7 @@ def test_golden_case(case, pa, oracle):
         # contig's steady state — the front end as ONE launch (k_front, phx_front.inc).  Every tap again.
         ann.run()
         st2, _, fl2 = ann.download_flat()
-        assert ann.front_runs() == (1 if len(seq) <= 128 << 10 else 0) and int(st2[0]) == status and fl2.tobytes() == genes.tobytes()
+        assert ann.front_runs() == (1 if len(seq) <= 40 << 10 else 0) and int(st2[0]) == status and fl2.tobytes() == genes.tobytes()
         check_contig(ann, 0, seq, o, fl2, int(st2[0]), kw, fp64_decides=not case.startswith("neartie"))
     ann.close()
 
@@ -227,7 +227,7 @@ def test_small_batches_fused_front_end_equals_the_staged_kernels(pa):
     contigs of mixed length, with a bad-letter contig, a too-short one and tRNA hits in the batch; 5 and 33 contigs stay staged."""
     rng = np.random.RandomState(8)
     for n in (1, 2, 3, 4, 5, 33):
-        seqs = [pa.synth_contig(3000 + 100 * n + i, int(rng.choice([600, 3000, 20000, 40000]))) for i in range(n)]  # (<= 128 kb in all: beyond, the staged kernels are used)
+        seqs = [pa.synth_contig(3000 + 100 * n + i, int(rng.choice([600, 3000, 6000, 9000] if n <= 4 else [600, 3000, 20000, 40000]))) for i in range(n)]  # (<= 40 kb in all: beyond, the staged kernels are used)
         if n >= 4:
             seqs[3] = b"acgtnnacgx" * 50
             seqs[1] = b"acgta"

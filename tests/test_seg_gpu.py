@@ -88,7 +88,7 @@ def test_small_batches_in_segments(pa):
 def test_staged_front_end_and_solvers_behind_their_planners(pa):
     """Up to 4 contigs run their front end as one launch (k_front) and the segments' solvers beside their planner wavefronts; PHX_CREATE_NO_FUSE
     keeps the staged kernels and launches the solvers behind the planners: the same records either way."""
-    seqs = [pa.synth_contig(70 + i, 30000 + 9000 * i) for i in range(3)]
+    seqs = [pa.synth_contig(70 + i, 11000 + 2000 * i) for i in range(3)]  # (39 kb in all: the fused front end takes up to 40 kb)
     f = _run(pa, seqs, (), 4, (0, 2))
     s = _run(pa, seqs, ("no_fuse",), 4, (0, 2))
     w = _run(pa, seqs, ("no_seg",), 2, (0, 2))

@@ -20,6 +20,8 @@ def batch(name):
     if name.startswith("short"):
         n = int(name[5:])
         return [pa.synth_contig(7 + i, 6000 + 500 * i) for i in range(n)]
+    if name.startswith("len"):
+        return [pa.synth_contig(5, int(name[3:]))]
     if name.startswith("synth"):
         n = int(name[5:])
         return [pa.synth_contig(i, 50000) for i in range(n)]
