@@ -1067,7 +1067,8 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     b.seg_nofb = (b.seg && c->seg_clean && !learn) ? 1 : 0;
     // behind k_front (up to 4 contigs) no edge fill is left to hide the segments' planner wavefronts: their solvers are launched beside them and
     // follow the window counts (DBatch.segw, cleared by k_reset at the head of this run); 128 pairs + 128 planner wavefronts are resident at once
-    b.seg_stream = (b.seg && fuse && !head_done && c->n <= 4 && !c->plan_stream_off && !c->one_stream && c->aux[3]) ? 1 : 0;
+    // (also behind the staged kernels of up to 4 contigs: Lambda's planner wavefronts take 50 us, the edge fill they run beside 38)
+    b.seg_stream = (b.seg && !head_done && !learn && c->n <= 4 && !c->plan_stream_off && !c->one_stream && c->aux[3]) ? 1 : 0;
     const bool stream_plan = stream_k >= 0;
     b.duo = c->duo ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
