@@ -285,7 +285,11 @@ void phxk_certify(const DBatch *b, int nl_mask, int vmax, void *stream) {
     if (nl_mask & 8) launch_certify<17>(b, vcap, s);
 }
 
-void phxk_refine(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_refine, dim3(b->n_contig), dim3(RF_T), 0, (hipStream_t)stream, *b); }
+void phxk_refine(const DBatch *b, void *stream) {
+    // (one workgroup per contig; a few long contigs — T4 alone: 29 000 edges, 15 rounds of its scan — get up to 16: 97 -> see DESIGN.md §7)
+    const unsigned y = b->n_contig <= 16 ? ysplit(b, 4) : 1u;
+    hipLaunchKernelGGL(k_refine, dim3(b->n_contig, y), dim3(RF_T), 0, (hipStream_t)stream, *b);
+}
 
 void phxk_gene_pack(const DBatch *b, void *stream) {
     const unsigned g = (unsigned)((b->n_contig + LMB_T - 1) / LMB_T);
