@@ -1070,7 +1070,9 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // (also behind the staged kernels of up to 4 contigs: Lambda's planner wavefronts take 50 us, the edge fill they run beside 38)
     b.seg_stream = (b.seg && !head_done && !learn && c->n <= 4 && !c->plan_stream_off && !c->one_stream && c->aux[3]) ? 1 : 0;
     const bool stream_plan = stream_k >= 0;
-    b.duo = c->duo ? 1 : 0;
+    // two wavefronts per contig while every contig has its pair of SIMD places at once (256 registers each: four workgroups per CU); beyond that the
+    // one-wavefront kernel keeps 1280 contigs resident against 1024 and wins: 1250 contigs 2.10 -> 1.93 ms, 2500 3.68 -> 3.58, 10 000 13.7 -> 13.3
+    b.duo = (c->duo && c->n <= c->n_simd) ? 1 : 0;
     b.plan_stream = stream_k < 0 ? 0 : (2 << stream_k); // the limb count of the class that streams (2, 4, 8)
     b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0; // node ids fit 21 bits (a contig has fewer nodes than positions)
     auto launch_plan = [&]() -> int { // the windows of the wavefront solver need the node records and in-edge counts only
