@@ -201,6 +201,7 @@ struct phx_ctx {
     bool seg_off = false;          // a contig of this batch could not be joined or proven (it was solved by one sweep in the same run): one sweep per contig until the next batch is uploaded
     bool seg_never = false;        //   ... and for good once that has happened to more than a quarter of the runs
     bool pend_seg = false;         // the run in flight uses segments
+    int pend_seg_k = 0;            //   ... at most this many per contig (the stride of DBatch.segw: phx_seg_stats)
     bool seg_clean = false;        // a run of this batch has proven every contig's segments: later runs of it do not launch the one sweep behind them
     int seg_max_n = 32;            // batches of up to this many contigs (env PHX_SEG_MAX_N): a contig that cannot be proven (~1 %) costs its one sweep on top,
                                    // and a batch waits for it: beyond ~32 contigs that eats the gain
@@ -1062,7 +1063,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     // Small batches: the 128-bit contigs of the wavefront solver in up to 16 segments each, all at once (phx_sssp_seg.inc); their planner
     // wavefronts are short (a sixteenth of a contig), so the solver is launched behind them as in a large batch.
     b.seg = (((mask >> 2) & 1) && seg_ready(c, b.caps)) ? seg_cap(c) : 0;
-    c->pend_seg = b.seg != 0;
+    c->pend_seg = b.seg != 0; c->pend_seg_k = b.seg;
     if (b.seg && stream_k == 0) stream_k = -1;
     b.seg_nofb = (b.seg && c->seg_clean && !learn) ? 1 : 0;
     // behind k_front (up to 4 contigs) no edge fill is left to hide the segments' planner wavefronts: their solvers are launched beside them and
@@ -2256,7 +2257,7 @@ int64_t phx_seg_fallbacks(phx_ctx *c) { return c ? c->seg_fallbacks : 0; }
 // (10 ns ticks), phases, packs, step-backs; returns the number of records written (0: the run did not use segments)
 int phx_seg_stats(phx_ctx *c, int32_t i, int32_t *out, int32_t cap_records) {
     if (!c || !out || i < 0 || i >= c->n || !c->ran || !c->pend_seg || !c->b_segw.p) return 0;
-    const int K = seg_cap(c) > 0 ? seg_cap(c) : 0;
+    const int K = c->pend_seg_k;
     const int n = std::min(K, (int)cap_records);
     if (n <= 0) return 0;
     if (hipMemcpy(out, (const int32_t *)c->b_segw.p + (size_t)i * (size_t)K * 8, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return 0;
