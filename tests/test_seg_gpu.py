@@ -4,6 +4,8 @@ improves its head, every reached node has a tight parent, the parents lead to th
 one-sweep solver (PHX_CREATE_NO_SEG) — records, distances, parents' path — and to exact python-int distances; a contig that cannot be
 proven is solved by one sweep in the same run and delivers the same."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -115,3 +117,48 @@ def test_margins_between_too_short_and_default(pa):
         for bp in ("500", "1500", "3000", "12000"):
             s = _run(pa, [seq], (), 2, (0,), env={"PHX_SEG_MARGIN_BP": bp})
             _same(s, w)
+
+
+SEG_WORKER = """
+import os, sys, time
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import phanotate_amd as pa
+from conftest import load_golden
+rank = int(sys.argv[1])
+seq = load_golden("NC_001416.1" if rank %% 2 == 0 else "NC_000866.1")[2]
+ref = pa.Annotator(flags=("no_seg",))
+want = ref.annotate_flat([seq])
+ref.close()
+ann = pa.Annotator()
+first = ann.annotate_flat([seq])
+assert all(a.tobytes() == b.tobytes() for a, b in zip(first, want)), "rank %%d: segments differ from one sweep" %% rank
+worst = 0.0
+for r in range(150):
+    t0 = time.perf_counter()
+    ann.run()
+    worst = max(worst, (time.perf_counter() - t0) * 1e3)
+    if r %% 10 == 0:
+        got = ann.download_flat()
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(got, want)), "rank %%d run %%d differs" %% (rank, r)
+print("SEG_OK", rank, ann.seg_runs(), ann.seg_fallbacks(), ann.plan_timeouts(), "%%.2f" %% worst, flush=True)
+"""
+
+
+def test_six_processes_of_lone_genomes_share_the_gpu(tmp_path):
+    """Six processes, each running Lambda or T4 alone 150 times: segments with their solvers beside their planner wavefronts while other
+    processes hold SIMDs.  Every downloaded result equals the one-sweep solver's; a planner time-out (28 ms, once) may switch a context
+    back to launching solvers behind planners, nothing more."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "seg_worker.py"
+    script.write_text(SEG_WORKER % (root, root))
+    procs = [subprocess.Popen([sys.executable, str(script), str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(6)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    lines = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-2000:]
+        lines += [l.split() for l in so.splitlines() if l.startswith("SEG_OK")]
+    assert len(lines) == 6
+    print("runs in segments, fallbacks, planner time-outs, worst run (ms):", [(int(l[2]), int(l[3]), int(l[4]), float(l[5])) for l in lines])
+    assert all(int(l[2]) > 0 for l in lines)
+    assert max(float(l[5]) for l in lines) < 400.0
