@@ -32,3 +32,12 @@ print("  feeder: packs with spill / side entries %.1f of %.1f" % (ft[:, 4].mean(
 ab = np.array([[x.rbs_background_count[j] for j in range(5)] for x in g]).astype(float)
 if ab[:, 2].sum() > 0:  # -DDUO_PROFILE_AB
     print("  phases A: %.1f per contig, %.3f us each; B: %.1f, %.3f us each; exact phases %.1f" % (ab[:, 2].mean(), ab[:, 0].sum() / ab[:, 2].sum() / 100.0, ab[:, 3].mean(), ab[:, 1].sum() / ab[:, 3].sum() / 100.0, ab[:, 4].mean()))
+print("  solver wavefront percentiles (us): " + " ".join("p%d %.0f" % (q, np.percentile(t, q)) for q in (10, 25, 50, 75, 90, 95, 98, 99, 100)))
+nn = np.array([x.n_node for x in g], float); ne = np.array([x.n_edge for x in g], float)
+print("  predictors of the solver's time: corr with nodes %.3f, with edges %.3f, with phases %.3f" % (np.corrcoef(t, nn)[0, 1], np.corrcoef(t, ne)[0, 1], np.corrcoef(t, it)[0, 1]))
+for frac in (0.25, 0.33, 0.5):
+    k = int(n * frac)
+    for nm, key in (("nodes", nn), ("edges", ne)):
+        A = set(np.argsort(-key)[:k].tolist())
+        rest = [i for i in range(n) if i not in A]
+        print("  slowest-first by %s, first %.0f %%: max of the rest %.0f us (of all: %.0f), contigs of the slowest 10 %% inside: %d of %d" % (nm, 100 * frac, t[rest].max(), t.max(), len(A & set(np.argsort(-t)[: n // 10].tolist())), n // 10))
