@@ -479,7 +479,7 @@ def main():
                 "step_frac_is": "SURVEY.md §8(d): sum of algorithmic bytes / sum of kernel time of one step (all stages, HIP events), / peak",
                 "runner_up": {"kernel": second, "avg_launch_ms": round(sec_total / max(sec_n, 1), 4), "frac": round(balgo / (sec_total / max(sec_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                               "traffic": traffic_of(second),
-                              "why": "the exact shortest path (k_sssp_duo) and the edge fill (k_edges<true>) take 0.40-0.43 ms each: which of the two is longer changes from run to run; both are measured with HIP events in the timed region"},
+                              "why": "the exact shortest path (k_sssp_duo; k_sssp_wave<2> beyond 1024 contigs per GPU) and the edge fill (k_edges<true>) take about as long as each other (0.40-0.43 ms per 1000 contigs): which of the two is longer changes from run to run; both are measured with HIP events in the timed region"},
             },
             "stage_ms_per_step": {k: round(v[0] / 3, 4) for k, v in stages_all.items() if v[1] > 0},
         }
