@@ -219,7 +219,10 @@ void phxk_orf_count(const DBatch *b, void *stream) {
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, YS_EMIT)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_bit_prefix(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b); }
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, YS_STATS)), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_score(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(b->mean_len >= 8192 ? NT : 64), 0, (hipStream_t)stream, *b); }
+void phxk_score(const DBatch *b, void *stream) {
+    if (b->n_contig <= 16 && b->mean_len >= 32768) { hipLaunchKernelGGL(k_score_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b); return; }
+    hipLaunchKernelGGL(k_score, dim3(b->n_contig), dim3(b->mean_len >= 8192 ? NT : 64), 0, (hipStream_t)stream, *b);
+}
 // node stage, part 1: needs the ORF / group records of k_orf<true> only (not their statistics), so the launcher runs it
 // beside k_orf_stats / k_score
 void phxk_nodes(const DBatch *b, void *stream) {
