@@ -1133,7 +1133,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
                     if ((early && mode == 1 && early_k(k)) || (roomy_side && k == 0 && mode <= 1)) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join[2], 0)); // after the side launches: it skips what the workgroup kernel solved there, and takes what the roomy wavefront kernel handed back
                     if (!(b.seg_stream && k == 0 && mode == 2)) phxk_sssp(&b, nl_of[k], mode, (size_t)lds[k], st);
                     if (b.seg && k == 0 && mode == 2) { // the segments' solvers: join, prove, parents; then one sweep for the contigs that could not be proven
-                        phxk_seg_merge(&b, st);
+                        phxk_seg_merge(&b, c->last_vmax, st);
                         if (!b.seg_nofb) phxk_seg_fallback(&b, st);
                     }
                 }

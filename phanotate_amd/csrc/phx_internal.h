@@ -342,7 +342,7 @@ void phxk_gene_pack(const DBatch *b, void *stream);
 void phxk_reset(const DBatch *b, const void *meta0, unsigned long long nbits_words, unsigned long long tbits_words, void *stream); // the head of a run: bitmaps, totals and per-contig records back to their start values
 int phxk_front_blocks_y(const DBatch *b); // workgroups per contig of k_front, 0: the batch is not one for it
 void phxk_front(const DBatch *b, void *stream); // small batches: ORF count ... edge fill in one launch (phx_front.inc)
-void phxk_seg_merge(const DBatch *b, void *stream); // DBatch.seg: after the segment solvers (phxk_sssp mode 2, 128 bits): join + proof + parents
+void phxk_seg_merge(const DBatch *b, int vmax, void *stream); // DBatch.seg: after the segment solvers (phxk_sssp mode 2, 128 bits): join + proof + parents
 int phxk_seg_kmax(void);
 void phxk_seg_fallback(const DBatch *b, void *stream); // ... and one sweep (k_wave_plan<2,0>, k_sssp_duo<0>) for the contigs k_seg_join / k_seg_close flagged (DMeta.seg_fail)
 void phxk_results(const DBatch *b, void *stream); // after every solver kernel of the run: parents as the reference's in-place Bellman-Ford leaves them

@@ -315,9 +315,14 @@ void phxk_front(const DBatch *b, void *stream) {
     const int y = phxk_front_blocks_y(b);
     if (y > 0) hipLaunchKernelGGL(k_front, dim3(b->n_contig, y), dim3(NT), 0, (hipStream_t)stream, *b);
 }
-void phxk_seg_merge(const DBatch *b, void *stream) {
-    int y = 2048 / (b->n_contig > 0 ? b->n_contig : 1);
-    y = y < 4 ? 4 : (y > 64 ? 64 : y);
+void phxk_seg_merge(const DBatch *b, int vmax, void *stream) {
+    // workgroups per contig of the join: one per 16 nodes of the largest contig the last run saw (a workgroup walks its share in rounds of four
+    // dependent loads: T4 on 64 workgroups took 5.4 rounds, 22 us), at most 4096 in all
+    const int n = b->n_contig > 0 ? b->n_contig : 1;
+    int y = vmax > 0 ? (vmax + SEGJ_T / SEGJ_LPN - 1) / (SEGJ_T / SEGJ_LPN) : 64;
+    const int cap = 4096 / n;
+    y = y > cap ? cap : y;
+    y = y < 4 ? 4 : y;
     hipLaunchKernelGGL(k_seg_join, dim3(b->n_contig, y), dim3(SEGJ_T), 0, (hipStream_t)stream, *b);
     hipLaunchKernelGGL(k_seg_close, dim3(b->n_contig), dim3(SEGM_T), 0, (hipStream_t)stream, *b);
 }
