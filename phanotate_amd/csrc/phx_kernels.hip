@@ -243,7 +243,8 @@ void phxk_nodes(const DBatch *b, void *stream) {
 void phxk_node_attr(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
-    hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(ES_T), 0, (hipStream_t)stream, *b);
+    if (b->n_contig <= 16 && b->mean_len >= 65536) hipLaunchKernelGGL(k_edges_scan_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b);
+    else hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(ES_T), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_tap(const DBatch *b, void *stream) { hipLaunchKernelGGL((k_edges<true, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
