@@ -229,7 +229,7 @@ void phxk_nodes(const DBatch *b, void *stream) {
 #ifndef NODES_STAGED
     // one workgroup per contig runs the four bodies in a row — unless the batch is a few LONG contigs (T4: one 256-thread workgroup then takes
     // 111 us and k_node_attr waits for it; the staged kernels spread coverage and records over four workgroups per contig: 60 us)
-    if (!(b->n_contig <= 16 && b->mean_len >= 65536)) {
+    if (!(b->n_contig <= 16 && b->mean_len >= 32768)) {
         hipLaunchKernelGGL(k_nodes_fused, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b);
         return;
     }
@@ -243,7 +243,7 @@ void phxk_nodes(const DBatch *b, void *stream) {
 void phxk_node_attr(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_node_attr, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_count(const DBatch *b, void *stream) {
     hipLaunchKernelGGL(k_edges<false>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
-    if (b->n_contig <= 16 && b->mean_len >= 65536) hipLaunchKernelGGL(k_edges_scan_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b);
+    if (b->n_contig <= 16 && b->mean_len >= 32768) hipLaunchKernelGGL(k_edges_scan_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b);
     else hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(ES_T), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
