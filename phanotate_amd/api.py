@@ -377,7 +377,7 @@ class Annotator:
         return int(self.L.phx_front_runs(self.h))
 
     def seg_runs(self):
-        """Runs whose 128-bit contigs were solved in segments side by side (phx_seg_runs; negative: switched off after a run that could not be proven)."""
+        """Runs whose 128-bit contigs were solved in segments side by side (phx_seg_runs)."""
         return int(self.L.phx_seg_runs(self.h))
 
     def seg_fallbacks(self):

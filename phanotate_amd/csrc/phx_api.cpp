@@ -171,7 +171,7 @@ struct phx_ctx {
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
-    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_mreach, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res, b_sord;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_mreach, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res, b_sord, b_gtab;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -194,6 +194,9 @@ struct phx_ctx {
     bool no_wave = false, always_sync = false;
     bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
+    int front_spins = 8000;        // FRONT_SPINS of k_front (env PHX_FRONT_SPINS at phx_create)
+    bool pend_cert = false;        // phx_run_async put the certificate kernels behind the run in flight: phx_download* will find it done
+    bool pend_front = false;       // the run in flight (or the captured graph) has k_front as its front end
     bool front_off = false;        // k_front once waited too long at a grid barrier on this context (its workgroups were not all resident): staged kernels from then on
     int64_t front_runs = 0;        // runs of this context whose front end was k_front (phx_front_runs)
     // small batches: a contig's shortest path by up to 16 wavefront pairs side by side, joined and proven by k_seg_merge (phx_sssp_seg.inc)
@@ -391,11 +394,14 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->dist_stride = c->n_limbs;
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
     b->esrcf = nullptr; b->ewf = nullptr;
+    b->gtab = (long long *)c->b_gtab.p;
+    b->gap_code = (c->duo && c->n <= c->n_simd) ? 1 : 0; // coded gap edges (4 bytes, no weight) where the solver of the batch's 128-bit contigs is k_sssp_duo, which reads the gap table (DBatch.duo, enqueue_run)
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->cint = (int32_t *)c->b_cint.p; b->csig = (uint64_t *)c->b_csig.p; b->cert_scale = c->cert_scale;
     b->eref = (DERef *)c->b_eref.p;
     b->path = (int32_t *)c->b_path.p;
     b->genes = (DGene *)c->b_genes.p;
+    b->front_spins = c->front_spins;
     b->gpack = gene_pack(c) ? 1 : 0;
     b->genes_c = b->genes ? b->genes + gene_half(c) : nullptr;
     b->gene_total = (uint32_t *)c->b_gtot.p;
@@ -471,6 +477,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32 + 512))) return rc; // (+ 48 time stamps of k_front in -DFRONT_PROFILE builds)
     if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
+    if ((rc = ensure(c, c->b_gtab, ((size_t)c->n + 1) * GT_N * 8))) return rc; // per contig: the weights of its coded gap edges (k_edges<true>)
     if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes) + sizeof(DTotals)))) return rc; // (k_results appends the totals: one copy brings both to the host)
     if (c->res_cap < (size_t)c->n + 1) {
         if (c->res) (void)hipHostFree(c->res);
@@ -612,6 +619,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->certify = (flags & PHX_CREATE_NO_CERTIFY) == 0;
     c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
     c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
+    { const char *e = getenv("PHX_FRONT_SPINS"); if (e && *e) c->front_spins = atoi(e); }
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_SEG_MAX_N"); if (e && atoi(e) >= 0) c->seg_max_n = atoi(e); }
@@ -660,7 +668,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_recs, &c->b_meta, &c->b_tiles, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord, &c->b_swin, &c->b_swrole, &c->b_sdist, &c->b_segw};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord, &c->b_gtab, &c->b_swin, &c->b_swrole, &c->b_sdist, &c->b_segw};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -972,6 +980,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     const uint32_t front_stages = (1u << ST_ORF_COUNT) | (1u << ST_ORF_EMIT) | (1u << ST_ORF_STATS) | (1u << ST_SCORE) | (1u << ST_NODES) | (1u << ST_EDGE_COUNT) | (1u << ST_EDGE_FILL);
     const bool fuse = !learn && !(c->prof && (c->prof_mask & front_stages)) && !c->no_fuse && !c->front_off && phxk_front_blocks_y(&b) > 0;
     DTotals *ht = c->h_tot;
+    c->pend_front = fuse; // (stands for the replays of the graph this enqueue is captured into: finish_once counts the runs)
     if (fuse) {
         b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0;
         phxk_front(&b, s);
@@ -1089,7 +1098,6 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     };
     if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
     if (!fuse) { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
-    else c->front_runs++;
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
@@ -1303,6 +1311,7 @@ int finish_once(phx_ctx *c) {
     c->tot_orf = ht->orf; c->tot_grp = ht->grp; c->tot_node = ht->node; c->tot_edge = ht->edge;
     c->have_plan = true;
     c->runs_on_layout++;
+    if (c->pend_front) c->front_runs++;
     return PHX_OK;
 }
 
@@ -1315,7 +1324,10 @@ int run_once(phx_ctx *c, bool learn) {
 int settle(phx_ctx *c) {
     if (!c->in_flight) return PHX_OK;
     c->in_flight = false;
+    const bool with_cert = c->pend_cert;
+    c->pend_cert = false;
     int rc = finish_once(c);
+    if (rc == PHX_OK && with_cert) { c->cert_done = true; c->meta_stale = true; } // (the certificate's kernels and its copy of the records were behind the run on the stream)
     for (int attempt = 0; rc == kRetry && attempt < 3; attempt++) rc = run_once(c, true);
     if (rc == kRetry) { c->err = "batch layout did not settle"; return PHX_E_STATE; }
     if (rc) return rc;
@@ -1360,6 +1372,7 @@ static void dev_report(phx_ctx *c) {
 }
 #endif
 
+static int enqueue_cert(phx_ctx *c); // (below, with the certificate)
 int phx_run_async(phx_ctx *c) {
     if (!c) return PHX_E_ARG;
     if (!c->uploaded) return PHX_E_STATE;
@@ -1372,6 +1385,14 @@ int phx_run_async(phx_ctx *c) {
     c->tot_orf = c->tot_grp = c->tot_node = c->tot_edge = 0;
     if ((rc = launch_once(c, false))) return rc;
     c->in_flight = true;
+    // The downloads that follow ask for the certificate (the reference's genes, §5c of DESIGN.md): behind the run on the stream it is
+    // done when they come, and with two batches in flight it runs beside the other context's kernels instead of holding the host up.
+    // (Sized and launched as the run itself: on what the last run of the context saw; a run that is repeated leaves it to the downloads.)
+    if (c->certify && c->exact) {
+        DCaps k;
+        current_caps(c, &k);
+        if (ensure(c, c->b_eref, ((size_t)k.edge + 16) * sizeof(DERef)) == PHX_OK && enqueue_cert(c) == PHX_OK) c->pend_cert = true;
+    }
     return PHX_OK;
 }
 
@@ -1494,10 +1515,7 @@ int phx_download_flat(phx_ctx *c, phx_gene *genes, int64_t cap, int64_t *offsets
 // distances, parent edges, path, edge records), not inside phx_run.  phx_download* ask for it (their gene lists are the reference's);
 // a caller that only wants the device's lists at full rate creates the context with PHX_CREATE_NO_EXACT (or phx_set_exact(ctx, 0)):
 // the downloads then skip it, phx_certified still computes it on demand.
-static int ensure_cert(phx_ctx *c) {
-    if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    { const int re = ensure(c, c->b_eref, ((size_t)c->tot_edge + 1) * sizeof(DERef)); if (re) return re; }
+static int enqueue_cert(phx_ctx *c) { // k_refine + k_certify + the records, on the context's stream (b_eref holds an entry for every edge the edge buffers hold)
     DBatch b;
     fill_batch(c, &b);
     int nlm = 0;
@@ -1510,6 +1528,13 @@ static int ensure_cert(phx_ctx *c) {
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->res, c->b_res.p, sizeof(DRes) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    return PHX_OK;
+}
+static int ensure_cert(phx_ctx *c) {
+    if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    { const int re = ensure(c, c->b_eref, ((size_t)c->tot_edge + 1) * sizeof(DERef)); if (re) return re; }
+    { const int rq = enqueue_cert(c); if (rq) return rq; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_timers(c);
     c->meta_stale = true;
@@ -1944,6 +1969,7 @@ static int ensure_tap_weights(phx_ctx *c) {
     b.esrcf = (uint32_t *)c->b_esrcf.p; b.ewf = (double *)c->b_ewf.p;
     b.defer_overlap = c->max_len < (1 << 21) ? 1 : 0;
     phxk_edges_tap(&b, c->stream);
+    phxk_edges_expand(&b, 0, 0, c->stream); // the taps (and the host re-solve) read DBatch.ew of every edge: the coded gap edges' weights from the gap tables
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tapw_valid = true;
@@ -2049,11 +2075,14 @@ static int ensure_exact(phx_ctx *c) {
     if (c->exact_done) return PHX_OK;
     try { // (nothing may cross the C-ABI as an exception: the vectors below and the worker threads can run out of memory)
     std::vector<int> todo;
-    { const int rm = fetch_meta(c); if (rm) return rm; }
-    // what the certificate left open, and the contigs no device kernel could take (DMeta.sssp_mode 4: path sums beyond 1088 bits)
+    // what the certificate left open, and the contigs no device kernel could take (DMeta.sssp_mode 4: path sums beyond 1088 bits — the
+    // only ones whose full record is needed here: the 0.5 KB per contig come over only when some contig reports that status)
+    bool any_overflow = false;
+    for (int i = 0; i < c->n && !any_overflow; i++) any_overflow = c->res[(size_t)i].status == PHX_S_OVERFLOW;
+    if (any_overflow) { const int rm = fetch_meta(c); if (rm) return rm; }
     for (int i = 0; i < c->n; i++) {
         const DRes &r = c->res[(size_t)i];
-        if ((r.status >= 0 && r.cert == 0) || (r.status == PHX_S_OVERFLOW && c->meta[(size_t)i].status == 0 && c->meta[(size_t)i].sssp_mode == 4)) todo.push_back(i);
+        if ((r.status >= 0 && r.cert == 0) || (r.status == PHX_S_OVERFLOW && any_overflow && c->meta[(size_t)i].status == 0 && c->meta[(size_t)i].sssp_mode == 4)) todo.push_back(i);
     }
     if (!todo.empty()) {
         std::vector<ExactIn> in(todo.size());
@@ -2250,13 +2279,21 @@ int phx_get_stage_ms(phx_ctx *c, float *ms, int32_t *launches, int reset) {
 const char *phx_stage_name(int k) { return k >= 0 && k < PHX_N_STAGES ? kStageName[k] : ""; }
 int64_t phx_seg_runs(phx_ctx *c) {
     if (!c) return 0;
+    if (c->in_flight && phx_wait(c)) return 0;
     return c->seg_runs;
 }
-int64_t phx_seg_fallbacks(phx_ctx *c) { return c ? c->seg_fallbacks : 0; }
+int64_t phx_seg_fallbacks(phx_ctx *c) {
+    if (!c) return 0;
+    if (c->in_flight && phx_wait(c)) return 0;
+    return c->seg_fallbacks;
+}
 // development: the records of the segments of contig `i` in the run last made — 8 ints each: windows | done flag, solver status, first node, end node, solver time
 // (10 ns ticks), phases, packs, step-backs; returns the number of records written (0: the run did not use segments)
 int phx_seg_stats(phx_ctx *c, int32_t i, int32_t *out, int32_t cap_records) {
-    if (!c || !out || i < 0 || i >= c->n || !c->ran || !c->pend_seg || !c->b_segw.p) return 0;
+    if (!c || !out) return 0;
+    if (c->in_flight && phx_wait(c)) return 0;
+    if (i < 0 || i >= c->n || !c->ran || !c->pend_seg || !c->b_segw.p) return 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return 0;
     const int K = c->pend_seg_k;
     const int n = std::min(K, (int)cap_records);
     if (n <= 0) return 0;

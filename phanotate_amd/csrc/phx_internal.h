@@ -33,7 +33,19 @@
 #define CLS_RT 4 // rev_comp(codon) in stop_codons
 // cls byte (DParams.cls_tab, the cls tap; no per-position array on the device): bits0-2 class, bits3-6 start-codon index (FS: of codon, RS: of rc codon), bit7 rc(codon) in start_codons
 
-#define ESRC_NODE(x) ((x) & 0x3fffffffu)
+// A gap edge whose weight is an entry of the contig's gap table (score_gap depends on the length and the strand pair only,
+// functions.py:36-46): bit 29, the table index ("code") in bits 19-28, the source node in bits 0-18 — such an edge has NO entry in
+// DBatch.ew (round 6: 69 % of the edges; k_edges<true> wrote 12 bytes for each).  Every other edge: source node in bits 0-28.
+#define ESRC_F_GAP 0x20000000u
+#define ESRC_GAP_NODES (1 << 19) // contigs with more nodes keep every edge in the explicit form
+#define ESRC_IS_GAP(x) (((x) >> 29) & 1u)
+#define ESRC_GAP_CODE(x) (((x) >> 19) & 1023u)
+#define ESRC_GAP_WORD(src, code) ((uint32_t)(src) | ESRC_F_GAP | ((uint32_t)(code) << 19))
+static inline __host__ __device__ uint32_t esrc_node(uint32_t x) { return x & ((x & ESRC_F_GAP) ? 0x7ffffu : 0x1fffffffu); }
+#define ESRC_NODE(x) esrc_node(x)
+#define GT_SAME 500 // gap table (DBatch.gtab, GT_N entries per contig): 0..499 same strand, length -2..497 (beyond 300: (1-pgap)^100 + length);
+#define GT_DIFF 303 //   500..802 across strands (+20), length -2..300
+#define GT_N 808
 #define ESRC_INEXACT(x) ((x) >> 31)
 #define ESRC_OFFPATH(x) (((x) >> 30) & 1u) // not for k_sssp_wave's common path: |W| >= 2^51, or the edge leaves the source node
 #define ESRC_F_INEXACT 0x80000000u
@@ -275,7 +287,10 @@ struct DBatch {
     int32_t dist_stride; // 64-bit words reserved per node in `dist` (max limbs of the batch)
     // per edge
     uint32_t *esrc;     // source node | off-path << 30 | inexact << 31 (ESRC_NODE / ESRC_OFFPATH / ESRC_INEXACT)
-    long long *ew;      // integer weight, encoded (ew_encode / ew_decode)
+    long long *ew;      // integer weight, encoded (ew_encode / ew_decode); nothing for an edge in the ESRC_F_GAP form until k_edges_expand fills it in
+    int32_t gap_code;   // 1: k_edges<true> writes gap edges in the coded form (the batch's 128-bit contigs go to k_sssp_duo, which reads the gap table; a batch for
+                        //    k_sssp_wave<2> — beyond one contig per SIMD pair — keeps plain rows: completing DBatch.ew for every contig cost more than the fill gained)
+    long long *gtab;    // per contig GT_N entries: the encoded integer weight of a gap edge by code (k_edges<true>)
     uint32_t *esrcf;    // tap variant of k_edges<true> only: plain source nodes and
     double *ewf;        //   fp64 weights, into scratch of their own
     const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge
@@ -306,6 +321,7 @@ struct DBatch {
     uint64_t *sdist;      // distances in the segments' own frames: SEG_KMAX slices of sdist_nodes nodes, 2 words each
     int64_t sdist_nodes;
     int32_t *segw;        // per (contig, segment): windows laid out (-1: none), status of its solver (0: done)
+    int32_t front_spins; // k_front: polls of a grid barrier before a workgroup raises front_abort (FRONT_SPINS; env PHX_FRONT_SPINS, -1: the first wait — the tests' way to the staged re-run)
     int32_t gpack;      // batches beyond 4096 contigs: gene records go to a fixed place per contig (grp_off + tn_off; no shared counter) and k_gene_pack moves them together into genes_c
     DGene *genes_c;
 };
@@ -329,6 +345,7 @@ void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_edges_expand(const DBatch *b, int n_limbs, int mode, void *stream); // DBatch.ew of the gap edges from the gap table: the contigs of limb class n_limbs that kernel `mode` solves (n_limbs 0: every contig)
 void phxk_edges_tap(const DBatch *b, void *stream); // k_edges<true> once more, writing fp64 weights and plain sources to DBatch.ewf / esrcf (taps)
 void phxk_sssp_order(const DBatch *b, void *stream);
 size_t phxk_sssp_lds_bytes(int V, int n_limbs);

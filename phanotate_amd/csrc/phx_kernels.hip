@@ -137,10 +137,11 @@ __device__ __forceinline__ bool cert_eps_is_zero_fast(double w, double c) {
 }
 #define CERT_C(b) ((b).cert_scale * 1.4210854715202004e-14) // 2^-46
 // one edge weight in registers: what goes to DBatch.ew (the encoded integer; the fp64 bits in the tap variant) and the inexact flag
-struct EWt { unsigned long long bits; uint32_t fl; };
+struct EWt { unsigned long long bits; uint32_t fl; int code; }; // code >= 0: an entry of the contig's gap table (the edge goes out in the ESRC_F_GAP form)
 template <bool TAPW>
 __device__ __forceinline__ EWt make_ew(double w, double c) {
     EWt r;
+    r.code = -1;
     if (TAPW) { r.bits = (unsigned long long)__double_as_longlong(w); r.fl = 0u; }
     else {
         r.bits = (unsigned long long)ew_encode(w);
@@ -148,6 +149,10 @@ __device__ __forceinline__ EWt make_ew(double w, double c) {
     }
     return r;
 }
+
+// the encoded integer weight of edge e (contig-relative) whose source word is sw: a coded gap edge (ESRC_F_GAP) has it in the contig's gap table
+__device__ __forceinline__ long long edge_wenc(uint32_t sw, const long long *ew, uint32_t e, const long long *gt) { return ESRC_IS_GAP(sw) ? gt[ESRC_GAP_CODE(sw)] : ew[e]; }
+__device__ __forceinline__ const long long *gtab_of(const DBatch &b, const DMeta *meta) { return b.gtab ? b.gtab + (size_t)(meta - b.meta) * GT_N : nullptr; } // (phx_solve: no table, no coded edge)
 
 // functions.py:174-178: both strands are counted, so Pa == Pt and Pg == Pc.
 __device__ __forceinline__ double contig_pstop(uint32_t gc, int L) {
@@ -196,7 +201,7 @@ void phxk_features_tap(const DBatch *b, int contig, uint32_t v_begin, uint32_t v
     hipLaunchKernelGGL((k_features<true, false>), dim3(g), dim3(64), 0, (hipStream_t)stream, *b, v_begin, v_end, tapbuf, contig);
 }
 void phxk_pack_planes(const DBatch *b, const void *letters, void *stream) {
-    if (b->n_contig > 0) hipLaunchKernelGGL(k_pack_planes, dim3(8, b->n_contig), dim3(64), 0, (hipStream_t)stream, *b, (const uint8_t *)letters);
+    if (b->n_contig > 0) hipLaunchKernelGGL(k_pack_planes, dim3(b->n_contig, 8), dim3(64), 0, (hipStream_t)stream, *b, (const uint8_t *)letters);
 }
 // Workgroups per contig of the per-contig kernels: `full` for the benchmark's 50 kb contigs, fewer for batches of short contigs
 // (a 2 kb contig has ~100 nodes: four workgroups of 256 threads would leave three idle), by the batch's mean contig length.
@@ -247,6 +252,7 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     else hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(ES_T), 0, (hipStream_t)stream, *b);
 }
 void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_expand(const DBatch *b, int nl, int mode, void *stream) { hipLaunchKernelGGL(k_edges_expand, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b, nl, mode); }
 void phxk_edges_tap(const DBatch *b, void *stream) { hipLaunchKernelGGL((k_edges<true, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 // phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents
 void phxk_sssp_only(const DBatch *b, int nl, void *stream) {
@@ -367,6 +373,9 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
 void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream) {
     dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
+    // k_sssp_duo reads the weights of the coded gap edges from the contig's gap table; every other solver kernel reads plain (source, weight)
+    // rows: DBatch.ew of the contigs it is about to take is completed first
+    if (!(mode == 2 && nl == 2 && b->duo) && b->gtab && b->gap_code) phxk_edges_expand(b, nl, mode, stream);
     if (mode == 2 || mode == 3) {
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)

@@ -240,7 +240,7 @@ def test_small_batches_fused_front_end_equals_the_staged_kernels(pa):
             a.run()
             a.run()
             a.run()  # (the third run on a layout replays the captured graph)
-            assert a.front_runs() == (2 if (mode == "fused" and n <= 4) else 0), (n, mode, a.front_runs())
+            assert a.front_runs() == (2 if (mode == "fused" and n <= 4) else 0), (n, mode, a.front_runs())  # (every run after the sizing one, the graph's replay included)
             flat = a.download_flat()
             taps = []
             for i in sorted(set([0, n // 2, n - 1] + ([3, 1] if n >= 4 else []))):
@@ -387,6 +387,25 @@ def test_attach_device_resident_input(pa):
         g = g2[o2[i] : o2[i + 1]]
         assert st[i] == s1 and all(np.array_equal(g[f], g1[f]) for f in ("left", "right", "strand", "frame"))
     tight.close()
+
+
+def test_attach_more_contigs_than_a_grid_has_rows(pa):
+    """70 000 tiny contigs through phx_attach: k_pack_planes packs the caller's letters with the contig index in gridDim.x (it
+    was gridDim.y, which ends at 65 535).  Same records as the upload path, which packs on the host."""
+    import torch
+
+    kinds = [pa.synth_contig(7000 + s, 100 + (s % 7) * 30) for s in range(350)]
+    seqs = [kinds[i % 350] for i in range(70000)]
+    ann = pa.Annotator()
+    want = ann.annotate_flat(seqs)
+    buf = torch.frombuffer(bytearray(b"".join(seqs)), dtype=torch.uint8).cuda()
+    offs = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    ann.attach(buf.data_ptr(), offs)
+    ann.run()
+    got = ann.download_flat()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(got, want))
+    assert int(want[1][-1]) > 0  # genes were called
+    ann.close()
 
 
 def _bellman_ford(V, src, dst, w, s, t):
