@@ -27,10 +27,13 @@
 extern "C" {
 #endif
 
-#define PHX_VERSION 400 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait;
+#define PHX_VERSION 410 /* 0.2.0: phx_create_ex, phx_set_trnas, phx_tap_dist, host I/O; phx_globals and PHX_N_STAGES grew; 0.2.1: phx_run_async, phx_wait;
                          * 0.3.0: phx_certified, phx_globals.certified, PHX_S_BADTRNA, more PHX_CREATE_* flags;
                          * 0.4.0: phx_params.start_w_text (the struct grew), phx_params_from_flags, the exact re-solve moved below the ABI
-                         *        (phx_download* deliver reference-exact genes; phx_certified reports 2), phx_dump_text, PHX_CREATE_NO_EXACT */
+                         *        (phx_download* deliver reference-exact genes; phx_certified reports 2), phx_dump_text, PHX_CREATE_NO_EXACT;
+                         *        (0.4.0 also REMOVED phx_rbs_table — an ABI break for a C caller that bound it: the table was a test hook of the Python Decimal
+                         *        replay, which moved to tests/decimal_replay.py and computes it itself);
+                         * 0.4.1: phx_run_async puts the certificate kernels behind the run unless exactness is off; env PHX_FRONT_SPINS (tests) */
 #define PHX_MAX_CODONS 16
 
 /* library-level errors */
@@ -146,7 +149,7 @@ typedef struct phx_globals {
                   * 0 none, 1 they exist and the solver's path already was the reference's, 2 the path was replaced by the reference's */
     int32_t certified; /* phx_certified's verdict for this contig (1 / 0 / -1) */
     /* the integer counters behind the fp64 globals above (what a Decimal restatement of the reference starts from, see
-     * phanotate_amd/dump.py): RBS bin counts without the pseudo-count (functions.py:155-156,168-169,211), GC-frame training
+     * tests/decimal_replay.py): RBS bin counts without the pseudo-count (functions.py:155-156,168-169,211), GC-frame training
      * counts (functions.py:261-279, index 1..3), g+c over the contig after the counting remap of functions.py:159-163 */
     uint32_t rbs_background_count[28], rbs_training_count[28];
     uint32_t gc_max_count[4], gc_min_count[4];
@@ -225,7 +228,11 @@ int phx_run(phx_ctx *ctx);                        /* every kernel of the path; b
  * batch two contexts alternating take 1.8 ms per batch instead of 2.3).  phx_run_async enqueues the run and returns; phx_wait
  * blocks until the results are in HBM and does what a run that did not fit needs (buffers grown, run repeated).  The first run
  * of a context is synchronous (it sizes the buffers between kernels).  Every other entry point on a context with a run in flight
- * waits for it first, so the pair is an optimisation, never a requirement.  phx_wait without a run: PHX_OK if results are there. */
+ * waits for it first, so the pair is an optimisation, never a requirement.  phx_wait without a run: PHX_OK if results are there.
+ * Unless exactness is off (PHX_CREATE_NO_EXACT / NO_CERTIFY, phx_set_exact(ctx, 0)) phx_run_async also enqueues the certificate kernels
+ * (k_refine, k_certify) behind the run on the context's stream: the download that follows finds the certificate done instead of waiting
+ * for it, and with two batches in flight it runs beside the other context's kernels (a stream of batches host to host: 2.6 -> 2.0 ms
+ * per 1000 x 50 kb).  phx_run never does: the certificate stays on demand there (phx_certified / phx_download*). */
 int phx_run_async(phx_ctx *ctx);
 int phx_wait(phx_ctx *ctx);
 /* Both download calls deliver gene lists that are the reference's: they ask for the certificate (phx_certified) and a contig the

@@ -185,6 +185,11 @@ class Annotator:
     def wait(self):
         self._chk(self.L.phx_wait(self.h), "phx_wait")
 
+    def set_exact(self, on):
+        """phx_set_exact: off — the downloads hand out the device's own lists (no certificate, no host re-solve) and run_async does not
+        put the certificate kernels behind the run."""
+        self._chk(self.L.phx_set_exact(self.h, 1 if on else 0), "phx_set_exact")
+
     def download_flat(self, exact=True):
         """(status int32[n], offsets int64[n+1], genes structured array[total]): genes of contig i are genes[offsets[i]:offsets[i+1]]
         in path order (phx_download_flat: no per-contig allocation).  The library delivers the reference's genes: a contig the device

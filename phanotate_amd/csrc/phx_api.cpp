@@ -195,6 +195,7 @@ struct phx_ctx {
     bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     int front_spins = 8000;        // FRONT_SPINS of k_front (env PHX_FRONT_SPINS at phx_create)
+    bool eager_cert = true;        // phx_run_async puts the certificate behind the run (env PHX_NO_EAGER_CERT=1: it does not)
     bool pend_cert = false;        // phx_run_async put the certificate kernels behind the run in flight: phx_download* will find it done
     bool pend_front = false;       // the run in flight (or the captured graph) has k_front as its front end
     bool front_off = false;        // k_front once waited too long at a grid barrier on this context (its workgroups were not all resident): staged kernels from then on
@@ -395,6 +396,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->esrc = (uint32_t *)c->b_esrc.p; b->ew = (long long *)c->b_ew.p; b->ewl = nullptr; b->ekey = nullptr;
     b->esrcf = nullptr; b->ewf = nullptr;
     b->gtab = (long long *)c->b_gtab.p;
+    b->gtabf = b->gtab ? (uint16_t *)(b->gtab + ((size_t)c->n + 1) * GT_N) : nullptr;
     b->gap_code = (c->duo && c->n <= c->n_simd) ? 1 : 0; // coded gap edges (4 bytes, no weight) where the solver of the batch's 128-bit contigs is k_sssp_duo, which reads the gap table (DBatch.duo, enqueue_run)
     b->tie = (uint8_t *)c->b_tie.p; b->tie_cap = cap_of(c->b_tie, 1, 0);
     b->cint = (int32_t *)c->b_cint.p; b->csig = (uint64_t *)c->b_csig.p; b->cert_scale = c->cert_scale;
@@ -477,7 +479,7 @@ int ensure_position_buffers(phx_ctx *c) {
     if ((rc = ensure(c, c->b_gtot, 64))) return rc;
     if ((rc = ensure(c, c->b_lpart, ((size_t)c->n / 256 + 2) * 32 + 512))) return rc; // (+ 48 time stamps of k_front in -DFRONT_PROFILE builds)
     if (sssp_ordered(c) && (rc = ensure(c, c->b_sord, (size_t)c->n * 4))) return rc;
-    if ((rc = ensure(c, c->b_gtab, ((size_t)c->n + 1) * GT_N * 8))) return rc; // per contig: the weights of its coded gap edges (k_edges<true>)
+    if ((rc = ensure(c, c->b_gtab, ((size_t)c->n + 1) * GT_N * 10))) return rc; // per contig: the weights of its coded gap edges (k_edges<true>)
     if ((rc = ensure(c, c->b_res, ((size_t)c->n + 1) * sizeof(DRes) + sizeof(DTotals)))) return rc; // (k_results appends the totals: one copy brings both to the host)
     if (c->res_cap < (size_t)c->n + 1) {
         if (c->res) (void)hipHostFree(c->res);
@@ -620,6 +622,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->exact = (flags & PHX_CREATE_NO_EXACT) == 0;
     c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
     { const char *e = getenv("PHX_FRONT_SPINS"); if (e && *e) c->front_spins = atoi(e); }
+    { const char *e = getenv("PHX_NO_EAGER_CERT"); c->eager_cert = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_SEG_MAX_N"); if (e && atoi(e) >= 0) c->seg_max_n = atoi(e); }
@@ -1388,7 +1391,7 @@ int phx_run_async(phx_ctx *c) {
     // The downloads that follow ask for the certificate (the reference's genes, §5c of DESIGN.md): behind the run on the stream it is
     // done when they come, and with two batches in flight it runs beside the other context's kernels instead of holding the host up.
     // (Sized and launched as the run itself: on what the last run of the context saw; a run that is repeated leaves it to the downloads.)
-    if (c->certify && c->exact) {
+    if (c->certify && c->exact && c->eager_cert) {
         DCaps k;
         current_caps(c, &k);
         if (ensure(c, c->b_eref, ((size_t)k.edge + 16) * sizeof(DERef)) == PHX_OK && enqueue_cert(c) == PHX_OK) c->pend_cert = true;
@@ -1533,7 +1536,7 @@ static int enqueue_cert(phx_ctx *c) { // k_refine + k_certify + the records, on 
 static int ensure_cert(phx_ctx *c) {
     if (!c->certify || c->cert_done || c->n == 0) return PHX_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    { const int re = ensure(c, c->b_eref, ((size_t)c->tot_edge + 1) * sizeof(DERef)); if (re) return re; }
+    { DCaps k; current_caps(c, &k); const int re = ensure(c, c->b_eref, ((size_t)std::max<int64_t>(c->tot_edge, k.edge) + 16) * sizeof(DERef)); if (re) return re; } // (an entry for every edge the edge buffers hold: phx_run_async sizes it the same way, before the run's edge count is known)
     { const int rq = enqueue_cert(c); if (rq) return rq; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     collect_timers(c);

@@ -290,7 +290,10 @@ struct DBatch {
     long long *ew;      // integer weight, encoded (ew_encode / ew_decode); nothing for an edge in the ESRC_F_GAP form until k_edges_expand fills it in
     int32_t gap_code;   // 1: k_edges<true> writes gap edges in the coded form (the batch's 128-bit contigs go to k_sssp_duo, which reads the gap table; a batch for
                         //    k_sssp_wave<2> — beyond one contig per SIMD pair — keeps plain rows: completing DBatch.ew for every contig cost more than the fill gained)
-    long long *gtab;    // per contig GT_N entries: the encoded integer weight of a gap edge by code (k_edges<true>)
+    long long *gtab;    // per contig GT_N entries: the encoded integer weight of a gap edge by table index (k_edges_scan: ONE workgroup per contig evaluates the 803 powers —
+                        //    until round 6 each of the four workgroups per contig of k_edges<true> did: 15 % of that kernel's VALU instructions); entry GT_N - 1: the
+                        //    bits of (1 - pgap)^100, GT_N - 2: some entry carries a flag
+    uint16_t *gtabf;    // per contig GT_N entries: the high part of a gap edge's source word, >> 19: flags (bits 11-12 <- 30-31) | coded (bit 10 <- ESRC_F_GAP) | code (bits 0-9)
     uint32_t *esrcf;    // tap variant of k_edges<true> only: plain source nodes and
     double *ewf;        //   fp64 weights, into scratch of their own
     const uint64_t *ewl; // optional integer weights (phx_solve), n_limbs words per edge

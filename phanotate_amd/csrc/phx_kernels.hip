@@ -222,7 +222,10 @@ void phxk_orf_count(const DBatch *b, void *stream) {
     else hipLaunchKernelGGL((k_orf<false, ORF_COUNT_T>), dim3(b->n_contig), dim3(ORF_COUNT_T), 0, (hipStream_t)stream, *b);
 }
 void phxk_orf_emit(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf<true>, dim3(b->n_contig, ysplit(b, YS_EMIT)), dim3(NT), 0, (hipStream_t)stream, *b); }
-void phxk_bit_prefix(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b); }
+void phxk_bit_prefix(const DBatch *b, void *stream) {
+    hipLaunchKernelGGL(k_bit_prefix, dim3(b->n_contig, 7), dim3(64), 0, (hipStream_t)stream, *b);
+    hipLaunchKernelGGL(k_gap_table, dim3(b->n_contig), dim3(NT), 0, (hipStream_t)stream, *b); // (needs the g+c counts of k_features only: here it hides beside the ORF scan)
+}
 void phxk_orf_stats(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_orf_stats, dim3(b->n_contig, ysplit(b, YS_STATS)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_score(const DBatch *b, void *stream) {
     if (b->n_contig <= 16 && b->mean_len >= 32768) { hipLaunchKernelGGL(k_score_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b); return; }
@@ -251,7 +254,10 @@ void phxk_edges_count(const DBatch *b, void *stream) {
     if (b->n_contig <= 16 && b->mean_len >= 32768) hipLaunchKernelGGL(k_edges_scan_big, dim3(b->n_contig), dim3(1024), 0, (hipStream_t)stream, *b);
     else hipLaunchKernelGGL(k_edges_scan, dim3(b->n_contig), dim3(ES_T), 0, (hipStream_t)stream, *b);
 }
-void phxk_edges_fill(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
+void phxk_edges_fill(const DBatch *b, void *stream) {
+    if (b->gap_code) hipLaunchKernelGGL((k_edges<true, false, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); // gap edges in the coded form
+    else hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
+}
 void phxk_edges_expand(const DBatch *b, int nl, int mode, void *stream) { hipLaunchKernelGGL(k_edges_expand, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b, nl, mode); }
 void phxk_edges_tap(const DBatch *b, void *stream) { hipLaunchKernelGGL((k_edges<true, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 // phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents

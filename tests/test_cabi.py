@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_errors():
     lib = _lib.lib()
-    assert lib.phx_version() == 400
+    assert lib.phx_version() == 410
     assert b"no CPU path" in lib.phx_strerror(-10)
     assert lib.phx_strerror(-2)
 

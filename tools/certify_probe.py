@@ -9,7 +9,7 @@ lo_e <= W* - W <= hi_e (k_refine, phx_refine.inc: the flagged edges once more in
   kappa[v] = last node on that path whose tree edge is flagged.  For every non-tree edge e = (u -> v) of a reached u:
   r(e) + sigma[u] - sigma[v] + lo_e > 0                        (r = d[u] + W_e - d[v], exact)
   or  r(e) == 0 and e not flagged and kappa[u] == kappa[v]     (a tie that is exact in the reference's integers too).
-The probe checks (1) that the bounds really hold W* on every edge (W* replayed by phanotate_amd/dump.py with Python's decimal), (2) how
+The probe checks (1) that the bounds really hold W* on every edge (W* replayed by tests/decimal_replay.py with Python's decimal), (2) how
 many contigs the certificate covers, (3) that for the covered ones the Decimal-derived in-order solve gives the same path."""
 import math
 import os

@@ -2,7 +2,7 @@
 """libphx's integer edge weights are trunc(fp64(w) * 1000), the reference hands fastpathz trunc(Decimal(w) * 1000) with
 28 digits.  For |w| beyond ~9e12 the two integers differ in their low digits, so a near-tie could resolve differently.  This
 tool measures it: for every contig it replays the reference's Decimal weights on the integers the GPU delivers
-(phanotate_amd/dump.py, the code behind the byte-exact --dump), solves the graph with the golden generator's in-order
+(tests/decimal_replay.py, the code behind the byte-exact --dump), solves the graph with the golden generator's in-order
 Bellman-Ford over Graph.iteredges order on those integers (python ints), and compares the node path with the one libphx returned.
 Run on the GPU box:   python tools/decimal_check.py [n_contigs] [seed] [max_len]"""
 import os, sys, time

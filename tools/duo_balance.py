@@ -32,6 +32,10 @@ print("  feeder: packs with spill / side entries %.1f of %.1f" % (ft[:, 4].mean(
 ab = np.array([[x.rbs_background_count[j] for j in range(5)] for x in g]).astype(float)
 if ab[:, 2].sum() > 0:  # -DDUO_PROFILE_AB
     print("  phases A: %.1f per contig, %.3f us each; B: %.1f, %.3f us each; exact phases %.1f" % (ab[:, 2].mean(), ab[:, 0].sum() / ab[:, 2].sum() / 100.0, ab[:, 3].mean(), ab[:, 1].sum() / ab[:, 3].sum() / 100.0, ab[:, 4].mean()))
+for i in np.argsort(-t)[:8]:
+    print("  slow contig %4d: %.0f us, packs %d, phases %d, nodes %d, edges %d; solver wait/take/phases/results %s; feeder part1/wait/part2/write %s, packs with side entries %d" % (i, t[i], packs[i], it[i], g[i].n_node, g[i].n_edge, " ".join("%.0f" % x for x in sp[i]), " ".join("%.0f" % (x / 100.0) for x in ft[i, :4]), ft[i, 4]))
+for i in np.argsort(t)[n // 2 - 2:n // 2 + 2]:
+    print("  median contig %4d: %.0f us, packs %d, phases %d, nodes %d, edges %d; solver wait/take/phases/results %s; feeder part1/wait/part2/write %s, packs with side entries %d" % (i, t[i], packs[i], it[i], g[i].n_node, g[i].n_edge, " ".join("%.0f" % x for x in sp[i]), " ".join("%.0f" % (x / 100.0) for x in ft[i, :4]), ft[i, 4]))
 print("  solver wavefront percentiles (us): " + " ".join("p%d %.0f" % (q, np.percentile(t, q)) for q in (10, 25, 50, 75, 90, 95, 98, 99, 100)))
 nn = np.array([x.n_node for x in g], float); ne = np.array([x.n_edge for x in g], float)
 print("  predictors of the solver's time: corr with nodes %.3f, with edges %.3f, with phases %.3f" % (np.corrcoef(t, nn)[0, 1], np.corrcoef(t, ne)[0, 1], np.corrcoef(t, it)[0, 1]))

@@ -1,5 +1,5 @@
 """The C replay of the reference's Decimal chain (csrc/phx_dec.c + phx_exact.inc) against the same replay with Python's own decimal
-(phanotate_amd/dump.py), edge by edge and contig by contig, on contigs no fixture holds:
+(tests/decimal_replay.py), edge by edge and contig by contig, on contigs no fixture holds:
   * phx_dump_text == dump.dump_lines: every edge's str(Decimal weight * 1000), byte for byte;
   * with the certificate's bounds inflated (cert_tight) every contig goes through the host re-solve: its genes == dump.python_resolve.
     python tools/exact_crosscheck.py [n_benchmark] [n_fuzz] [seed]"""
