@@ -45,7 +45,7 @@ def algorithmic_bytes(sz):
     return sz["L"] / 4.0 + 4.0 * sz["L"] + 64.0 * sz["n_orf"] + 32.0 * sz["n_edge"] + 64.0 * sz["n_node"]
 
 
-STAGE_KERNEL = {"sssp": ("k_sssp_duo<0,", "k_sssp_wave<2, 0,"), "features": "k_features", "edges_fill": "k_edges<true, false>", "edges_count": "k_edges<false, false>",
+STAGE_KERNEL = {"sssp": ("k_sssp_duo<0,", "k_sssp_wave<2, 0,"), "features": "k_features", "edges_fill": ("k_edges<true, false, true>", "k_edges<true, false, false>"), "edges_count": "k_edges<false, false, false>",
                 "orf_stats": "k_orf_stats", "orf_emit": "k_orf<true,", "orf_count": "k_orf<false,", "nodes": "k_node_build", "score": "k_score",
                 "inorder": "k_inorder<2,"}  # substrings of the kernel names as rocprofv3 prints them (several: the first that occurs — k_sssp_duo, or k_sssp_wave<2> under PHX_NO_DUO)
 

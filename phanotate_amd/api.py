@@ -246,19 +246,19 @@ class Annotator:
         self.upload(seqs)
         if trnas is not None:
             self.set_trnas(trnas)
-        self.run()
+        self.run_async()  # (the certificate the download asks for goes behind the run on the stream; the download waits for both)
         return self.download()
 
     def annotate_flat(self, seqs):
         """The same as three flat arrays, see download_flat."""
         self.upload(seqs)
-        self.run()
+        self.run_async()
         return self.download_flat()
 
     def annotate_flat_raw(self, ptrs, lens, keep=None):
         """annotate_flat for a caller that holds the C-ABI's own arguments: the contigs' addresses (uint64[n]) and lengths (int64[n])."""
         self.upload_raw(ptrs, lens, keep)
-        self.run()
+        self.run_async()
         return self.download_flat()
 
     def dump_text(self, i):

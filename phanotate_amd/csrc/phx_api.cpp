@@ -1700,7 +1700,7 @@ int phx_set_exact(phx_ctx *c, int on) {
 int phx_annotate(phx_ctx *c, int32_t n, const char *const *seq, const int64_t *len, phx_result *out) {
     int rc = phx_upload(c, n, seq, len);
     if (rc) return rc;
-    if ((rc = phx_run(c))) return rc;
+    if ((rc = phx_run_async(c))) return rc; // (with the certificate behind the run on the stream: the download asks for it; the first run of a context is synchronous)
     return phx_download(c, out);
 }
 
