@@ -171,7 +171,7 @@ struct phx_ctx {
     DevBuf b_meta0;          // the per-contig records as a run starts (layout fields set, accumulators zero): copied over b_meta on the device at the start of every run
     bool meta0_dirty = true; // batch layout changed since b_meta0 was written
     int runs_on_layout = 0;  // completed runs since the batch layout last changed (a graph is captured from the second on)
-    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_mreach, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res, b_sord, b_gtab;
+    DevBuf b_node, b_parent, b_inoff, b_no, b_npos, b_ehit, b_mreach, b_olist, b_dist, b_esrc, b_ew, b_ewl, b_path, b_genes, b_gtot, b_tot, b_lpart, b_res, b_sord, b_gtab, b_erank;
     DTotals *h_tot = nullptr; // pinned
     bool have_plan = false;    // a run completed on this context: its buffers, solver classes and LDS sizes are the first guess for the next
     int last_mask = 0;
@@ -347,6 +347,7 @@ void current_caps(const phx_ctx *c, DCaps *k) {
     v = std::min(v, cap_of(c->b_no, 8, 8));
     v = std::min(v, cap_of(c->b_npos, 4, 8));
     v = std::min(v, cap_of(c->b_ehit, 8, 8));
+    v = std::min(v, cap_of(c->b_erank, 16, 8));
     v = std::min(v, cap_of(c->b_mreach, 16, 8));
     v = std::min(v, cap_of(c->b_inoff, 4, 8 + (int64_t)c->n + 1));
     v = std::min(v, cap_of(c->b_dist, 8 * (size_t)limbs, 8));
@@ -385,6 +386,7 @@ void fill_batch(phx_ctx *c, DBatch *b) {
     b->no = (double *)c->b_no.p;
     b->npos = (int32_t *)c->b_npos.p;
     b->ehit = (uint64_t *)c->b_ehit.p;
+    b->erank = (int4 *)c->b_erank.p;
     b->mreach = (uint32_t *)c->b_mreach.p;
     b->olist = (int32_t *)c->b_olist.p;
     b->win = (DWin *)c->b_win.p; b->wrole = (uint2 *)c->b_wrole.p;
@@ -671,7 +673,7 @@ void phx_destroy(phx_ctx *c) {
     c->in_flight = false;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->b_eref, &c->b_cint, &c->b_csig, &c->b_meta0, &c->b_tie, &c->b_ekey, &c->b_tnode, &c->b_tedge, &c->b_tnid, &c->b_tbits, &c->b_win, &c->b_wrole, &c->b_bridge, &c->b_recs, &c->b_meta, &c->b_tiles, &c->b_nbits, &c->b_nbase, &c->b_cbits, &c->b_orf, &c->b_ostat, &c->b_oweight, &c->b_owi, &c->b_oflag, &c->b_ewf, &c->b_esrcf, &c->b_onode, &c->b_grp, &c->b_bits, &c->b_cpre, &c->b_bpre, &c->b_item, &c->b_iprev,
-                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord, &c->b_gtab, &c->b_swin, &c->b_swrole, &c->b_sdist, &c->b_segw};
+                     &c->b_node, &c->b_parent, &c->b_inoff, &c->b_no, &c->b_npos, &c->b_ehit, &c->b_mreach, &c->b_olist, &c->b_dist, &c->b_esrc, &c->b_ew, &c->b_ewl, &c->b_path, &c->b_genes, &c->b_gtot, &c->b_tot, &c->b_lpart, &c->b_res, &c->b_sord, &c->b_gtab, &c->b_erank, &c->b_swin, &c->b_swrole, &c->b_sdist, &c->b_segw};
     for (DevBuf *b : all) release(*b);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
@@ -1018,6 +1020,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         if ((rc = ensure(c, c->b_no, NV * 8))) return rc;
         if ((rc = ensure(c, c->b_npos, NV * 4))) return rc;
         if ((rc = ensure(c, c->b_ehit, NV * 8))) return rc;
+        if ((rc = ensure(c, c->b_erank, NV * 16))) return rc;
         if ((rc = ensure(c, c->b_mreach, NV * 16))) return rc;
         if ((rc = ensure(c, c->b_dist, NV * 8 * (size_t)std::max(c->n_limbs, 2)))) return rc;
         if (c->certify) {

@@ -279,6 +279,8 @@ struct DBatch {
     DWin *win;          // k_wave_plan -> k_sssp_wave: window records,
     uint2 *wrole;       //   WIN_ROLES lane records per window
     int32_t *olist;     // per contig V-1 node ids: open nodes, the target, close nodes (k_node_order -> k_edges)
+    int4 *erank;        // per open CDS node: the id ranges of its two neighbour scans — gap edges [x, y], overlap candidates [z, w] — as the counting pass ranked them
+                        //    (k_edges<false> -> k_edges<true>: four rank queries of three gathers each that the filling pass need not repeat)
     uint64_t *ehit;     // per node: verdicts of its first 64 overlap-edge candidates (k_edges<false> -> k_edges<true>)
     uint32_t *mreach;   // per node, 4 x node capacity: the lowest node an overlap (backward) edge out of this close node ends in (0xffffffff: none).
                         //   k_node_attr presets, k_edges<false> fills three partial arrays (see there), k_edges_scan leaves their minimum in the
