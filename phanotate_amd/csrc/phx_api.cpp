@@ -115,7 +115,7 @@ struct phx_ctx {
     bool in_flight = false;      // phx_run_async has enqueued a run that phx_wait has not collected yet
     int pend_mask = 0;
     int64_t pend_lds[4] = {0, 0, 0, 0};
-    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_fork_orf = nullptr, ev_join_orf = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -195,6 +195,7 @@ struct phx_ctx {
     bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     int front_spins = 8000;        // FRONT_SPINS of k_front (env PHX_FRONT_SPINS at phx_create)
+    bool orf_rows = true;          // the ORF edges' rows by k_edges_orf beside the edge fill (env PHX_NO_ORF_ROWS=1: by k_edges<true> itself)
     bool eager_cert = true;        // phx_run_async puts the certificate behind the run (env PHX_NO_EAGER_CERT=1: it does not)
     bool pend_cert = false;        // phx_run_async put the certificate kernels behind the run in flight: phx_download* will find it done
     bool pend_front = false;       // the run in flight (or the captured graph) has k_front as its front end
@@ -625,6 +626,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     c->no_fuse = (flags & PHX_CREATE_NO_FUSE) != 0;
     { const char *e = getenv("PHX_FRONT_SPINS"); if (e && *e) c->front_spins = atoi(e); }
     { const char *e = getenv("PHX_NO_EAGER_CERT"); c->eager_cert = !(e && e[0] == '1'); }
+    { const char *e = getenv("PHX_NO_ORF_ROWS"); c->orf_rows = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_SEG_MAX_N"); if (e && atoi(e) >= 0) c->seg_max_n = atoi(e); }
@@ -651,7 +653,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
         hipEventCreateWithFlags(&c->ev_piece[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_piece[1], hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+        hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork_orf, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_orf, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     { // the reference's default codon tables (file_handling.py:51-53): k_features then uses their formulas instead of the table walk
@@ -696,6 +699,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->ev_fork_nodes) (void)hipEventDestroy(c->ev_fork_nodes);
     if (c->ev_join_nodes) (void)hipEventDestroy(c->ev_join_nodes);
     if (c->ev_fork_pre) (void)hipEventDestroy(c->ev_fork_pre);
+    if (c->ev_fork_orf) (void)hipEventDestroy(c->ev_fork_orf);
+    if (c->ev_join_orf) (void)hipEventDestroy(c->ev_join_orf);
     if (c->ev_join_pre) (void)hipEventDestroy(c->ev_join_pre);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1103,7 +1108,15 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
         return PHX_OK;
     };
     if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
-    if (!fuse) { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); }
+    // the rows of the close CDS nodes (the ORF edges) by a thread per ORF on a side stream, beside the neighbour scans of the open nodes
+    b.orf_rows = (!fuse && c->orf_rows && !c->one_stream && c->aux[2]) ? 1 : 0;
+    if (b.orf_rows) {
+        HIPCHK(c, hipEventRecord(c->ev_fork_orf, s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork_orf, 0));
+        phxk_edges_orf(&b, c->aux[2]);
+        HIPCHK(c, hipEventRecord(c->ev_join_orf, c->aux[2]));
+    }
+    if (!fuse) { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); if (b.orf_rows) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_orf, 0)); }
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to

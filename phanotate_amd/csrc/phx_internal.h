@@ -290,6 +290,8 @@ struct DBatch {
     // per edge
     uint32_t *esrc;     // source node | off-path << 30 | inexact << 31 (ESRC_NODE / ESRC_OFFPATH / ESRC_INEXACT)
     long long *ew;      // integer weight, encoded (ew_encode / ew_decode); nothing for an edge in the ESRC_F_GAP form until k_edges_expand fills it in
+    int32_t orf_rows;   // 1: the rows of the close CDS nodes (the ORF edges, functions.py:311-318) are written by k_edges_orf, a thread per ORF, on a side stream beside
+                        //    k_edges<true>, which then stops at the open nodes
     int32_t gap_code;   // 1: k_edges<true> writes gap edges in the coded form (the batch's 128-bit contigs go to k_sssp_duo, which reads the gap table; a batch for
                         //    k_sssp_wave<2> — beyond one contig per SIMD pair — keeps plain rows: completing DBatch.ew for every contig cost more than the fill gained)
     long long *gtab;    // per contig GT_N entries: the encoded integer weight of a gap edge by table index (k_edges_scan: ONE workgroup per contig evaluates the 803 powers —
@@ -350,6 +352,7 @@ void phxk_edges_count(const DBatch *b, void *stream);
 void phxk_layout1(const DBatch *b, void *stream); // after orf_count: ORF / group / node offsets, totals
 void phxk_layout2(const DBatch *b, void *stream); // after edges_count: edge offsets, integer class and solver per contig, totals
 void phxk_edges_fill(const DBatch *b, void *stream);
+void phxk_edges_orf(const DBatch *b, void *stream); // DBatch.orf_rows: the ORF edges' rows, a thread per ORF (beside phxk_edges_fill)
 void phxk_edges_expand(const DBatch *b, int n_limbs, int mode, void *stream); // DBatch.ew of the gap edges from the gap table: the contigs of limb class n_limbs that kernel `mode` solves (n_limbs 0: every contig)
 void phxk_edges_tap(const DBatch *b, void *stream); // k_edges<true> once more, writing fp64 weights and plain sources to DBatch.ewf / esrcf (taps)
 void phxk_sssp_order(const DBatch *b, void *stream);

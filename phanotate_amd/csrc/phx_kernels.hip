@@ -258,6 +258,7 @@ void phxk_edges_fill(const DBatch *b, void *stream) {
     if (b->gap_code) hipLaunchKernelGGL((k_edges<true, false, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); // gap edges in the coded form
     else hipLaunchKernelGGL(k_edges<true>, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b);
 }
+void phxk_edges_orf(const DBatch *b, void *stream) { hipLaunchKernelGGL(k_edges_orf, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 void phxk_edges_expand(const DBatch *b, int nl, int mode, void *stream) { hipLaunchKernelGGL(k_edges_expand, dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b, nl, mode); }
 void phxk_edges_tap(const DBatch *b, void *stream) { hipLaunchKernelGGL((k_edges<true, true>), dim3(b->n_contig, ysplit(b, 4)), dim3(NT), 0, (hipStream_t)stream, *b); }
 // phx_solve: relaxation, path walk (no genes: DBatch.genes is null), in-order parents
