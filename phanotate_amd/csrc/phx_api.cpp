@@ -115,7 +115,7 @@ struct phx_ctx {
     bool in_flight = false;      // phx_run_async has enqueued a run that phx_wait has not collected yet
     int pend_mask = 0;
     int64_t pend_lds[4] = {0, 0, 0, 0};
-    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_fork_orf = nullptr, ev_join_orf = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_fork_plan = nullptr, ev_fork_nodes = nullptr, ev_join_nodes = nullptr, ev_fork_pre = nullptr, ev_join_pre = nullptr, ev_fork_orf = nullptr, ev_join_orf = nullptr, ev_fork_score = nullptr, ev_join_score = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     phx_params params;
     std::string err;
     // device constants
@@ -195,6 +195,7 @@ struct phx_ctx {
     bool no_fuse = false;          // PHX_CREATE_NO_FUSE: small batches through the staged kernels as well
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     int front_spins = 8000;        // FRONT_SPINS of k_front (env PHX_FRONT_SPINS at phx_create)
+    bool side_score = true;        // k_score on a side stream beside k_node_attr and the edge count (env PHX_NO_SIDE_SCORE=1: in line)
     bool orf_rows = true;          // the ORF edges' rows by k_edges_orf beside the edge fill (env PHX_NO_ORF_ROWS=1: by k_edges<true> itself)
     bool eager_cert = true;        // phx_run_async puts the certificate behind the run (env PHX_NO_EAGER_CERT=1: it does not)
     bool pend_cert = false;        // phx_run_async put the certificate kernels behind the run in flight: phx_download* will find it done
@@ -627,6 +628,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     { const char *e = getenv("PHX_FRONT_SPINS"); if (e && *e) c->front_spins = atoi(e); }
     { const char *e = getenv("PHX_NO_EAGER_CERT"); c->eager_cert = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_ORF_ROWS"); c->orf_rows = !(e && e[0] == '1'); }
+    { const char *e = getenv("PHX_NO_SIDE_SCORE"); c->side_score = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_SEG_MAX_N"); if (e && atoi(e) >= 0) c->seg_max_n = atoi(e); }
@@ -654,7 +656,8 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork_plan, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_nodes, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork_pre, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_pre, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork_orf, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_orf, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
+        hipEventCreateWithFlags(&c->ev_fork_orf, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_orf, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork_score, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join_score, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return fail(PHX_E_HIP); }
     DParams dp;
     build_dparams(params, &dp);
     { // the reference's default codon tables (file_handling.py:51-53): k_features then uses their formulas instead of the table walk
@@ -700,6 +703,8 @@ void phx_destroy(phx_ctx *c) {
     if (c->ev_join_nodes) (void)hipEventDestroy(c->ev_join_nodes);
     if (c->ev_fork_pre) (void)hipEventDestroy(c->ev_fork_pre);
     if (c->ev_fork_orf) (void)hipEventDestroy(c->ev_fork_orf);
+    if (c->ev_fork_score) (void)hipEventDestroy(c->ev_fork_score);
+    if (c->ev_join_score) (void)hipEventDestroy(c->ev_join_score);
     if (c->ev_join_orf) (void)hipEventDestroy(c->ev_join_orf);
     if (c->ev_join_pre) (void)hipEventDestroy(c->ev_join_pre);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1045,9 +1050,16 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     phxk_nodes(&b, c->aux[1]);
     HIPCHK(c, hipEventRecord(c->ev_join_nodes, c->aux[1]));
     { StageTimer t(c, ST_ORF_STATS); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_pre, 0)); phxk_orf_stats(&b, s); }
-    { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
+    // the ORF weights are needed by k_layout2 (integer class) and by the edge fill, not by the node attributes or the edge count: beside them
+    const bool side_score = c->side_score && !c->one_stream && c->aux[0] && !learn;
+    if (side_score) {
+        HIPCHK(c, hipEventRecord(c->ev_fork_score, s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_score, 0));
+        { StageTimer t(c, ST_SCORE, c->aux[0]); phxk_score(&b, c->aux[0]); }
+        HIPCHK(c, hipEventRecord(c->ev_join_score, c->aux[0]));
+    } else { StageTimer t(c, ST_SCORE); phxk_score(&b, s); }
     { StageTimer t(c, ST_NODES); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_nodes, 0)); phxk_node_attr(&b, s); }
-    { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); phxk_layout2(&b, s); }
+    { StageTimer t(c, ST_EDGE_COUNT); phxk_edges_count(&b, s); if (side_score) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_score, 0)); phxk_layout2(&b, s); }
     HIPCHK(c, hipGetLastError());
     mask = c->last_mask;
     for (int k = 0; k < 4; k++) lds[k] = c->last_lds[k];
