@@ -1051,7 +1051,11 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     HIPCHK(c, hipEventRecord(c->ev_join_nodes, c->aux[1]));
     { StageTimer t(c, ST_ORF_STATS); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_pre, 0)); phxk_orf_stats(&b, s); }
     // the ORF weights are needed by k_layout2 (integer class) and by the edge fill, not by the node attributes or the edge count: beside them
-    const bool side_score = c->side_score && !c->one_stream && c->aux[0] && !learn;
+    // (large batches only: a side stream costs an event round trip — 10 us of a lone genome's 330 —, and with more streams than hardware queues a side
+    //  stream's kernel may sit behind another side stream's: behind the planner, which outlasts the edge fill below ~500 contigs — Lambda 0.34 -> 0.39 ms,
+    //  64 x 50 kb 0.78 -> 0.91 with k_edges_orf on its side stream, profiles/r06_side_streams_small.txt)
+    const bool big_batch = c->n >= 600;
+    const bool side_score = c->side_score && big_batch && !c->one_stream && c->aux[0] && !learn;
     if (side_score) {
         HIPCHK(c, hipEventRecord(c->ev_fork_score, s));
         HIPCHK(c, hipStreamWaitEvent(c->aux[0], c->ev_fork_score, 0));
@@ -1121,7 +1125,7 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     };
     if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
     // the rows of the close CDS nodes (the ORF edges) by a thread per ORF on a side stream, beside the neighbour scans of the open nodes
-    b.orf_rows = (!fuse && c->orf_rows && !c->one_stream && c->aux[2]) ? 1 : 0;
+    b.orf_rows = (!fuse && c->orf_rows && c->n >= 600 && !c->one_stream && c->aux[2]) ? 1 : 0; // (large batches only, see k_score above)
     if (b.orf_rows) {
         HIPCHK(c, hipEventRecord(c->ev_fork_orf, s));
         HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork_orf, 0));
