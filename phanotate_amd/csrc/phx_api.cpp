@@ -196,6 +196,7 @@ struct phx_ctx {
     bool duo = true;               // 128-bit contigs: k_sssp_duo (feeder + solver wavefront) instead of k_sssp_wave<2> (PHX_CREATE_NO_DUO, env PHX_NO_DUO=1: off)
     int front_spins = 8000;        // FRONT_SPINS of k_front (env PHX_FRONT_SPINS at phx_create)
     bool side_score = true;        // k_score on a side stream beside k_node_attr and the edge count (env PHX_NO_SIDE_SCORE=1: in line)
+    int orf_stream = 1;            // which side stream k_edges_orf takes (env PHX_ORF_STREAM: 0..3; -1: the main stream, in front of the edge fill)
     bool orf_rows = true;          // the ORF edges' rows by k_edges_orf beside the edge fill (env PHX_NO_ORF_ROWS=1: by k_edges<true> itself)
     bool eager_cert = true;        // phx_run_async puts the certificate behind the run (env PHX_NO_EAGER_CERT=1: it does not)
     bool pend_cert = false;        // phx_run_async put the certificate kernels behind the run in flight: phx_download* will find it done
@@ -628,6 +629,7 @@ int phx_create_ex(const phx_params *params, int device, void *stream, uint32_t f
     { const char *e = getenv("PHX_FRONT_SPINS"); if (e && *e) c->front_spins = atoi(e); }
     { const char *e = getenv("PHX_NO_EAGER_CERT"); c->eager_cert = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_ORF_ROWS"); c->orf_rows = !(e && e[0] == '1'); }
+    { const char *e = getenv("PHX_ORF_STREAM"); if (e && *e) { const int v = atoi(e); if (v >= -1 && v <= 3) c->orf_stream = v; } }
     { const char *e = getenv("PHX_NO_SIDE_SCORE"); c->side_score = !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_DUO"); c->duo = !(flags & PHX_CREATE_NO_DUO) && !(e && e[0] == '1'); }
     { const char *e = getenv("PHX_NO_SEG"); c->seg_on = !(flags & PHX_CREATE_NO_SEG) && !(e && e[0] == '1'); }
@@ -1125,14 +1127,16 @@ int enqueue_run(phx_ctx *c, bool learn, int &mask, int64_t lds[4]) {
     };
     if ((rc = launch_plan())) return rc; // beside the edge fill (started after it, beside the solver: the fill gains what the solver loses)
     // the rows of the close CDS nodes (the ORF edges) by a thread per ORF on a side stream, beside the neighbour scans of the open nodes
-    b.orf_rows = (!fuse && c->orf_rows && c->n >= 600 && !c->one_stream && c->aux[2]) ? 1 : 0; // (large batches only, see k_score above)
-    if (b.orf_rows) {
+    b.orf_rows = (!fuse && c->orf_rows && c->n >= 600 && !c->one_stream && c->aux[2]) ? 1 : 0; // (large batches only, see k_score above; aux[1]: the node kernels' stream, idle by now — behind the planner's stream or on aux[2] the kernel ran AFTER the planner, profiles/r06_orf_stream.txt)
+    const bool orf_side = b.orf_rows && c->orf_stream >= 0;
+    if (orf_side) {
+        hipStream_t so = c->aux[c->orf_stream];
         HIPCHK(c, hipEventRecord(c->ev_fork_orf, s));
-        HIPCHK(c, hipStreamWaitEvent(c->aux[2], c->ev_fork_orf, 0));
-        phxk_edges_orf(&b, c->aux[2]);
-        HIPCHK(c, hipEventRecord(c->ev_join_orf, c->aux[2]));
+        HIPCHK(c, hipStreamWaitEvent(so, c->ev_fork_orf, 0));
+        phxk_edges_orf(&b, so);
+        HIPCHK(c, hipEventRecord(c->ev_join_orf, so));
     }
-    if (!fuse) { StageTimer t(c, ST_EDGE_FILL); phxk_edges_fill(&b, s); if (b.orf_rows) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_orf, 0)); }
+    if (!fuse) { StageTimer t(c, ST_EDGE_FILL); if (b.orf_rows && !orf_side) phxk_edges_orf(&b, s); phxk_edges_fill(&b, s); if (orf_side) HIPCHK(c, hipStreamWaitEvent(s, c->ev_join_orf, 0)); }
     {
         // one stream per limb class that occurs in the batch (the classes are disjoint sets of contigs); within it the
         // wavefront kernel first, then the kernels it may hand contigs to
