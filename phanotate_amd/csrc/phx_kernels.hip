@@ -380,8 +380,9 @@ void phxk_wave_plan(const DBatch *b, int wide_too, void *stream) {
 void phxk_sssp(const DBatch *b, int nl, int mode, size_t lds_bytes, void *stream) {
     dim3 g(b->n_contig), t(NT);
     hipStream_t s = (hipStream_t)stream;
-    // (k_sssp_duo reads the weights of the coded gap edges from the contig's gap table; every other solver kernel reads plain (source, weight) rows and
-    //  completes DBatch.ew of the contigs it takes itself: expand_contig)
+    // k_sssp_duo reads the weights of the coded gap edges from the contig's gap table; every other solver kernel reads plain (source, weight) rows:
+    // k_sssp_lds and k_sssp complete DBatch.ew of the contigs they take themselves (expand_contig), k_sssp_wave gets it completed by a launch in front of it
+    if ((mode == 2 || mode == 3) && !(mode == 2 && nl == 2 && b->duo) && b->gtab && b->gap_code) phxk_edges_expand(b, nl, mode, stream);
     if (mode == 2 || mode == 3) {
         if (nl == 2 && mode == 2 && b->duo) { // two wavefronts per contig: the feeder prepares the windows, the solver runs the phases (phx_sssp_duo.inc).
             // (The roomy configuration — the few contigs whose windows need more spill entries than the tight one holds — stays with k_sssp_wave<2, 1>.)
