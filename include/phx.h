@@ -303,7 +303,7 @@ int phx_dump_text(phx_ctx *ctx, int32_t contig, char **text, int64_t *text_len);
 /* ---- the solver alone (the fastpathz boundary, phanotate.py:56-64) ----
  * Edges (src[i] -> dst[i]) over nodes 0..V-1 with integer weights given as n_limbs little-endian
  * 64-bit words each (two's complement).  Writes the node ids of the shortest path source..target to
- * path_out (cap entries) and its length to *n_path (0 if unreachable). */
+ * path_out (cap entries) and its length to *n_path (0 if unreachable).  V < 2^29 (PHX_E_ARG beyond). */
 int phx_solve(phx_ctx *ctx, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs,
               int32_t n_limbs, int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path,
               uint64_t *dist_limbs);

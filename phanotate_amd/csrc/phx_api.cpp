@@ -2207,6 +2207,7 @@ int phx_dump_text(phx_ctx *c, int32_t contig, char **text, int64_t *text_len) {
 int phx_solve(phx_ctx *c, int32_t V, int32_t E, const int32_t *src, const int32_t *dst, const uint64_t *w_limbs, int32_t n_limbs,
               int32_t source, int32_t target, int32_t *path_out, int32_t cap, int32_t *n_path, uint64_t *dist_limbs) {
     if (!c || V < 2 || E < 0 || (E > 0 && (!src || !dst || !w_limbs)) || !n_path) return PHX_E_ARG;
+    if (V >= (1 << 29)) return PHX_E_ARG; // (a source word holds 29 bits of node id: bit 29 marks a coded gap edge, phx_internal.h)
     if (!(n_limbs == 2 || n_limbs == 4 || n_limbs == 8 || n_limbs == 17)) return PHX_E_ARG;
     if (source < 0 || source >= V || target < 0 || target >= V || source == target) return PHX_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
