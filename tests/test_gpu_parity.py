@@ -408,6 +408,44 @@ def test_attach_more_contigs_than_a_grid_has_rows(pa):
     ann.close()
 
 
+def test_large_batch_side_streams_equal_small_batches(pa):
+    """Batches of 600 contigs or more write the ORF edges' rows by k_edges_orf (a thread per ORF, on a side stream beside the neighbour scans of the open
+    nodes) and run k_score beside k_node_attr; smaller batches keep everything in k_edges<true> on one stream.  720 contigs with tRNA hits on every fifth,
+    a bad-letter and a too-short contig among them: genes, and the tapped ORF / node / edge tables of a sample, equal to the same contigs in batches of 90."""
+    rng = np.random.RandomState(66)
+    seqs = [pa.synth_contig(66000 + i, int(rng.choice([900, 3000, 8000, 15000]))) for i in range(720)]
+    seqs[17] = b"acgtnnacgx" * 60
+    seqs[401] = b"acgta"
+    hits = [[(100, 180), (400, 320)] if (i % 5 == 0 and len(s) > 1000) else [] for i, s in enumerate(seqs)]
+    sample = [0, 5, 17, 100, 401, 640, 719]
+
+    def run(lo, hi):
+        a = pa.Annotator()
+        a.upload(seqs[lo:hi])
+        a.set_trnas(hits[lo:hi])
+        a.run()
+        a.run()  # (steady state)
+        st, offs, genes = a.download_flat()
+        taps = {}
+        for i in sample:
+            if lo <= i < hi:
+                gl = a.globals(i - lo)
+                taps[i] = (gl.n_orf, gl.n_node, gl.n_edge, a.orfs(i - lo).tobytes(), a.nodes(i - lo).tobytes(), a.edges(i - lo).tobytes())
+        per = [(int(st[k]), genes[offs[k]:offs[k + 1]].tobytes()) for k in range(hi - lo)]
+        a.close()
+        return per, taps
+
+    big, big_taps = run(0, 720)
+    small, small_taps = [], {}
+    for lo in range(0, 720, 90):
+        p, t = run(lo, lo + 90)
+        small += p
+        small_taps.update(t)
+    assert big == small
+    assert big_taps == small_taps
+    assert sum(1 for s_, g in big if s_ == 0 and g) > 600
+
+
 def _bellman_ford(V, src, dst, w, s, t):
     dist = [None] * V
     par = [-1] * V
