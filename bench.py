@@ -386,11 +386,12 @@ def main():
             else:
                 dt_pipe = max_over_ranks(time.perf_counter() - t0)
     if world == 1 and not args.no_pipeline and not args.no_pipeline_host:
-        for _ in pipe.run([seqs, seqs]):
+        raw = (h_ptrs, h_lens, seqs_b)  # (the C-ABI's own arguments, as in the one-context region above: a C caller has them)
+        for _ in pipe.run([raw, raw]):
             pass
         barrier()
         t0 = time.perf_counter()
-        for _ in pipe.run([seqs] * args.steps):
+        for _ in pipe.run([raw] * args.steps):
             pass
         barrier()
         dt_pipe_host = time.perf_counter() - t0
