@@ -333,7 +333,7 @@ def main():
     # on demand from the state a run leaves on the device: its cost on top of a run, and how many contigs it covers
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ann.run()
+        ann.run_async()  # (the certificate kernels behind the run on the stream, as every caller that goes on to download has them: no host round trip between the two)
         cert = ann.certified()
     dt_cert = max_over_ranks(time.perf_counter() - t0)
     n_uncert = int(sum_over_ranks(float((cert != 1).sum())))   # not proven on the device
@@ -453,7 +453,7 @@ def main():
             },
             "certificate": {"ms_per_step_with_run": round(dt_cert / args.steps * 1e3, 4), "ms_on_top_of_run": round((dt_cert - dt) / args.steps * 1e3, 4), "contigs_not_certified_on_device": n_uncert,
                             "contigs_solved_again_on_host": n_again,
-                            "what": "phx_run + phx_certified per step: k_refine evaluates the edges fp64 could not place between two integers once more in double-double (bounds on the reference's integers from the error of its own 28-digit chain), k_certify proves per contig, in exact integers, that the gene list is the one the reference's Decimal-derived integers give (phx_refine.inc, phx_certify.inc); a contig it cannot prove is solved again on the host in the reference's own arithmetic, inside the library (phx_exact.inc).  Computed on demand, so `value` does not contain it; `host_to_host` (phx_download_flat asks for it) does"},
+                            "what": "phx_run_async + phx_certified per step: k_refine evaluates the edges fp64 could not place between two integers once more in double-double (bounds on the reference's integers from the error of its own 28-digit chain), k_certify proves per contig, in exact integers, that the gene list is the one the reference's Decimal-derived integers give (phx_refine.inc, phx_certify.inc); a contig it cannot prove is solved again on the host in the reference's own arithmetic, inside the library (phx_exact.inc).  Computed on demand, so `value` does not contain it; `host_to_host` (phx_download_flat asks for it) does"},
             "host_to_host": {
                 "value": round(bp_total * args.steps / dt_host / 1e6, 3),
                 "unit": "Mbp/s",
